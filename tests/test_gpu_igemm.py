@@ -1,0 +1,158 @@
+"""GPU parity of the MFMA implicit-GEMM family (tg_igemm_f32 / tg_wgrad_f32) against the
+oracle's conv / transposed-conv / dense, through the C ABI.  fp32 tolerance: the kernel
+accumulates in exact fp32 in a different order than NumPy's BLAS -> |err| <= 2e-5 * sum|a||b| scale."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _tg():
+    from tg import lib, geom
+    lib.load()
+    return lib, geom
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def padc(x, ld):
+    out = np.zeros(x.shape[:-1] + (ld,), np.float32)
+    out[..., :x.shape[-1]] = x
+    return out
+
+
+def close(a, b, scale):
+    err = np.abs(a - b).max()
+    assert err <= 3e-5 * scale, (err, scale)
+
+
+CONV_CASES = [  # n,h,w,cin,cout,k,stride,pad
+    (3, 8, 8, 32, 32, 3, 1, 'SAME'),
+    (5, 16, 16, 64, 128, 3, 1, 'SAME'),
+    (2, 32, 32, 13, 32, 3, 1, 'SAME'),      # cond-concat channel count, padded to 32
+    (3, 32, 32, 42, 64, 3, 2, 'SAME'),      # stride 2, asymmetric SAME
+    (4, 8, 8, 96, 64, 3, 1, 'VALID'),
+    (2, 6, 6, 64, 96, 1, 1, 'SAME'),        # NiN
+    (7, 9, 7, 40, 32, 3, 2, 'SAME'),        # ragged sizes, M not a tile multiple
+]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,s,pad", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad):
+    lib, geom = _tg()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((k, k, cin, cout)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    ci_p, co_p = geom.pad32(cin), geom.pad32(cout)
+    y_ref = T.lrelu(T.conv2d(x, wt, (s, s), pad) + bias)
+    ho, wo = y_ref.shape[1:3]
+    scale = np.abs(x).max() * np.abs(wt).max() * k * k * cin
+
+    # forward: OTI weights [co_p][k*k][ci_p]
+    w_oti = np.zeros((co_p, k * k, ci_p), np.float32)
+    w_oti[:cout, :, :cin] = wt.reshape(k * k, cin, cout).transpose(2, 0, 1)
+    xd, wd, bd = dev(padc(x, ci_p)), dev(w_oti), dev(padc(bias, co_p))
+    yd = torch.full((n, ho, wo, co_p), 7.0, device='cuda')
+    d = geom.conv_fwd(n, h, w, ci_p, co_p, k, s, pad, act='lrelu')
+    lib.call("tg_igemm_f32", d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
+    y = yd.cpu().numpy()
+    close(y[..., :cout], y_ref, scale)
+    assert (y[..., cout:] == 0).all()
+
+    # input gradient: padded HWIO weights [k*k][ci_p][co_p]
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = T.conv2d_bwd_input(x.shape, wt, dy, (s, s), pad)
+    w_hwio = np.zeros((k * k, ci_p, co_p), np.float32)
+    w_hwio[:, :cin, :cout] = wt.reshape(k * k, cin, cout)
+    dyd, whd = dev(padc(dy, co_p)), dev(w_hwio)
+    dxd = torch.full((n, h, w, ci_p), 7.0, device='cuda')
+    descs = geom.conv_dgrad(n, h, w, ci_p, co_p, k, s, pad)
+    assert len(descs) == s * s
+    for dd in descs:
+        lib.call("tg_igemm_f32", dd, lib.ptr(dyd), lib.ptr(whd), None, lib.ptr(dxd), lib.cur_stream())
+    dx = dxd.cpu().numpy()
+    close(dx[..., :cin], dx_ref, np.abs(dy).max() * np.abs(wt).max() * k * k * cout)
+    assert (dx[..., cin:] == 0).all()
+
+    # filter gradient, 3 pixel splits summed on the host
+    dw_ref = T.conv2d_bwd_filter(x, dy, wt.shape, (s, s), pad)
+    nsplit = 3
+    slab = torch.full((nsplit, k * k, ci_p, co_p), 7.0, device='cuda')
+    dw_desc = geom.conv_wgrad(n, h, w, ci_p, co_p, k, s, pad)
+    lib.call("tg_wgrad_f32", dw_desc, lib.ptr(xd), lib.ptr(dyd), lib.ptr(slab), nsplit, lib.cur_stream())
+    dw = slab.cpu().numpy().sum(0)
+    close(dw[:, :cin, :cout].reshape(wt.shape), dw_ref, np.abs(x).max() * np.abs(dy).max() * n * ho * wo)
+    assert (dw[:, cin:, :] == 0).all() and (dw[:, :, cout:] == 0).all()
+
+
+DECONV_CASES = [(3, 4, 4, 42, 64), (2, 8, 8, 74, 3), (5, 4, 4, 522, 256)]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", DECONV_CASES)
+def test_deconv5x5s2_fwd_dgrad_wgrad(n, h, w, cin, cout):
+    lib, geom = _tg()
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((5, 5, cout, cin)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    ci_p, co_p = geom.pad32(cin), geom.pad32(cout)
+    y_ref = np.tanh(T.conv2d_transpose(x, wt) + bias)
+    w_pad = np.zeros((25, co_p, ci_p), np.float32)
+    w_pad[:, :cout, :cin] = wt.reshape(25, cout, cin)
+    xd, wd, bd = dev(padc(x, ci_p)), dev(w_pad), dev(padc(bias, co_p))
+    # store only the logical channels (ld_out = cout) — the generator's last layer writes [N,32,32,3]
+    yd = torch.full((n, 2 * h, 2 * w, cout), 7.0, device='cuda')
+    for d in geom.deconv_fwd(n, h, w, ci_p, co_p, ld_out=cout, n_store=cout, act='tanh'):
+        lib.call("tg_igemm_f32", d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
+    close(yd.cpu().numpy(), y_ref, np.abs(x).max() * np.abs(wt).max() * 9 * cin)
+
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dyd = dev(padc(dy, co_p))
+    dx_ref = T.conv2d_transpose_bwd_input(wt, dy)
+    w_t = np.zeros((25, ci_p, co_p), np.float32)
+    w_t[:, :cin, :cout] = wt.reshape(25, cout, cin).transpose(0, 2, 1)
+    dxd = torch.full((n, h, w, ci_p), 7.0, device='cuda')
+    wtd = dev(w_t)
+    lib.call("tg_igemm_f32", geom.deconv_dgrad(n, h, w, ci_p, co_p), lib.ptr(dyd), lib.ptr(wtd), None,
+             lib.ptr(dxd), lib.cur_stream())
+    close(dxd.cpu().numpy()[..., :cin], dx_ref, np.abs(dy).max() * np.abs(wt).max() * 25 * cout)
+
+    dw_ref = T.conv2d_transpose_bwd_filter(x, dy, wt.shape)
+    slab = torch.full((2, 25, co_p, ci_p), 7.0, device='cuda')
+    lib.call("tg_wgrad_f32", geom.deconv_wgrad(n, h, w, co_p, ci_p), lib.ptr(dyd), lib.ptr(xd), lib.ptr(slab), 2,
+             lib.cur_stream())
+    dw = slab.cpu().numpy().sum(0)
+    close(dw[:, :cout, :cin].reshape(wt.shape), dw_ref, np.abs(x).max() * np.abs(dy).max() * n * h * w)
+
+
+def test_dense_and_identity_layout():
+    """A = I with an asymmetric B catches a transposed C-write (cdna_hip_programming.md §3)."""
+    lib, geom = _tg()
+    m, kdim, nout = 200, 128, 96
+    rng = np.random.default_rng(2)
+    x = np.zeros((m, kdim), np.float32)
+    x[np.arange(128), np.arange(128)] = 1
+    x[128:] = rng.standard_normal((m - 128, kdim))
+    wt = rng.standard_normal((nout, kdim)).astype(np.float32)      # Wt[n][k]
+    yd = torch.zeros((m, nout), device='cuda')
+    xd, wd = dev(x), dev(wt)      # keep the device buffers alive across the asynchronous launch
+    lib.call("tg_igemm_f32", geom.dense_fwd(m, kdim, nout), lib.ptr(xd), lib.ptr(wd), None, lib.ptr(yd),
+             lib.cur_stream())
+    y = yd.cpu().numpy()
+    np.testing.assert_array_equal(y[:128], wt.T)                    # exact: one product per output
+    close(y[128:], x[128:] @ wt.T, np.abs(x).max() * np.abs(wt).max() * kdim)
+
+
+def test_bad_descriptor_is_rejected():
+    lib, geom = _tg()
+    d = geom.dense_fwd(4, 32, 32)
+    d.ld_in = 30
+    x = torch.zeros(4, 32, device='cuda')
+    with pytest.raises(lib.TgError, match="ld_in"):
+        lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(x), None, lib.ptr(x), lib.cur_stream())
