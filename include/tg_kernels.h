@@ -91,6 +91,119 @@ int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const 
  * slab holds n_split*n_taps*ld_in*c_out floats; deterministic (no atomics). */
 int tg_wgrad_f32(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream);
 
+/* ---- parameter-side kernels ---------------------------------------------------------------------- */
+/* scale[c] = g[c] * rsqrt(max(sum_r V[r][c]^2, 1e-12)), V row-major [rows][c].
+ * tf.nn.l2_normalize(V,[0,1,2])*g of conv2d_WN (Model/nn.py:502) and g/sqrt(sum V^2) of dense_WN (nn.py:554). */
+int tg_wn_scale_f32(const float* v, const float* g, int rows, int c, float* scale, void* stream);
+
+/* Re-layout of a filter src[t][a][b] (b contiguous; optional per-b `scale`) with zero channel padding:
+ *   dst_same[t][a][b]            -> [t][a_pad][b_pad]         (may be NULL)
+ *   dst_tr[b*tr_sb + t*tr_st + a] for b < b_pad, a < a_pad   (may be NULL)
+ * HWIO conv filter -> OTI for tg_igemm_f32 forward (tr_sb = t*a_pad, tr_st = a_pad) and padded HWIO for the
+ * input-gradient; [kh,kw,Cout,Cin] transposed-conv filter -> padded copy and per-tap transpose. */
+int tg_filter_prep_f32(const float* src, const float* scale, int t, int a, int b, int a_pad, int b_pad, float* dst_same, float* dst_tr,
+                       int64_t tr_sb, int64_t tr_st, void* stream);
+
+/* dst[t][c][n] = sum_s slab[s][t][c][n] (c < c_dim, n < n_dim): finishes tg_wgrad_f32, drops channel padding. */
+int tg_slab_reduce_f32(const float* slab, int n_split, int t, int c_pad, int n_pad, int c_dim, int n_dim, float* dst, void* stream);
+
+/* gradients of W = g V/||V|| given dW (all row-major [rows][c]); coef = scratch of 2*c floats.
+ * Autodiff of Model/nn.py:502,554 emitted by optimizer.minimize (Training/train_base.py:65). */
+int tg_wn_bwd_f32(const float* dw, const float* v, const float* g, int rows, int c, float* dv, float* dg, float* coef, void* stream);
+
+/* ---- statistics / normalisation (HBM-bound) ------------------------------------------------------ */
+/* Rows of a batched activation belong to up to 8 consecutive "application segments" (one per classifier /
+ * discriminator application batched into the launch); seg_rows is a HOST array of nseg row counts. */
+int64_t tg_colstats_workspace_floats(int rows, int nseg, int c);
+/* Per-(segment, channel) sums, deterministic two-stage reduction.  mode 0: s1 = sum a; 1: s1 = sum a, s2 = sum a^2;
+ * 2: s1 = sum a*act'(b) (b = activation output); 3: s1 = sum a, s2 = sum a*b.  s1/s2: [nseg][c].
+ * tf.nn.moments of mean_only_batch_norm_impl (Model/nn.py:171-175), tf.contrib.layers.batch_norm
+ * (Model/modle_base.py:229-237), bias-gradient reductions. */
+int tg_colstats_f32(int mode, const float* a, int ld_a, const float* b, int ld_b, int rows, int c, const int32_t* seg_rows, int nseg, int act,
+                    float alpha, float* workspace, float* s1, float* s2, void* stream);
+/* y[r][k] = act(x[r][k]*scale[k] + shift[seg(r)][k]) for k < c, 0 for c <= k < c_zero_to (scale may be NULL). */
+int tg_seg_scale_shift_act_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int c, int c_zero_to, const int32_t* seg_rows, int nseg,
+                               const float* scale, const float* shift, int act, float alpha, void* stream);
+/* dx[r][k] = dy[r][k]*act'(yact[r][k]) + shift[seg(r)][k]: backward of mean-only BN + nonlinearity. */
+int tg_seg_actgrad_shift_f32(const float* dy, int ld_dy, const float* yact, int ld_y, float* dx, int ld_dx, int rows, int c,
+                             const int32_t* seg_rows, int nseg, const float* shift, int act, float alpha, void* stream);
+/* mean-only BN (Model/nn.py:147-187): train: shift[s][k] = b[k] - sums[s][k]/rows_s and pop_mean <- decay*pop_mean +
+ * (1-decay)*mean_s sequentially over s; eval (train = 0): shift[s][k] = b[k] - pop_mean[k]. */
+int tg_mobn_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, int rows, int c, const float* b, float* pop_mean, float decay,
+                         int train, float* shift, void* stream);
+/* shift[s][k] = -sums[s][k]/rows_s; db[k] = sum_s sums[s][k]. */
+int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, int rows, int c, float* shift, float* db, void* stream);
+/* batch norm (training mode, biased variance): scale = gamma*inv, shift = beta - mean*scale, mean_inv = [mean | inv];
+ * moving statistics updated in place when non-NULL (bessel = use the unbiased variance, the fused 4-D kernel). */
+int tg_bn_finalize_f32(const float* s1, const float* s2, int rows, int c, const float* gamma, const float* beta, float eps, float* scale,
+                       float* shift, float* mean_inv, float* moving_mean, float* moving_var, float decay, int bessel, void* stream);
+/* from s_dy = sum dy, s_dyx = sum dy*x: dgamma, dbeta and abc = [A | B | C] with dx = A*dy + B*x + C. */
+int tg_bn_bwd_finalize_f32(const float* s_dy, const float* s_dyx, int rows, int c, const float* gamma, const float* mean_inv, float* abc,
+                           float* dgamma, float* dbeta, void* stream);
+/* dx = (A*dy + B*x + C) * (relu_mask ? x > 0 : 1): BN backward fused with the ReLU that precedes it in the generator
+ * (ReLU -> BN order, Model/Good_GAN_cifar10.py:41-42). */
+int tg_bn_bwd_apply_f32(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const float* abc,
+                        int relu_mask, void* stream);
+
+/* ---- pointwise / pooling / concat ---------------------------------------------------------------- */
+/* out[r][:c] = x[r][:c] + add[r][:c] (add may be NULL), zero up to ld_out.  Gaussian input noise of the classifier
+ * (Model/modle_base.py:193-202 via Good_GAN_cifar10.py:104) + channel padding. */
+int tg_pad_add_f32(const float* x, int ld_x, int c, const float* add, int ld_add, float* out, int ld_out, int rows, void* stream);
+/* out[n,p,:] = [x[n,p,:c]*mask*mscale, y[n,:ncls], 0...]: dropout (modle_base.py:190-191) + _conv_cond_concat
+ * (modle_base.py:239-244).  mask may be NULL. */
+int tg_cond_concat_f32(const float* x, int ld_x, int c, const float* mask, int ld_mask, float mscale, const float* y, int ncls, float* out,
+                       int ld_out, int n_img, int hw, void* stream);
+/* out[r][:c] = dy[r][:c]*mask*mscale*act'(yact[r][:c]), zero up to ld_out (mask, yact may be NULL). */
+int tg_actgrad_f32(const float* dy, int ld_dy, const float* yact, int ld_y, const float* mask, int ld_mask, float mscale, float* out, int ld_out,
+                   int rows, int c, int act, float alpha, void* stream);
+/* tf.nn.max_pool 2x2 s2 (Good_GAN_cifar10.py:123,142) fused with the dropout that follows (:124,143). */
+int tg_maxpool2_fwd_f32(const float* y, int ld_y, float* out, int ld_out, const float* mask, int ld_mask, float mscale, int n, int h, int w, int c,
+                        void* stream);
+int tg_maxpool2_bwd_f32(const float* dout, int ld_do, const float* mask, int ld_mask, float mscale, const float* y, int ld_y, float* dy, int ld_dy,
+                        int n, int h, int w, int c, void* stream);
+/* global MAX pool (the layer named avg_pool_0, Good_GAN_cifar10.py:163); pads of out are zeroed. */
+int tg_gmaxpool_fwd_f32(const float* x, int ld_x, float* out, int ld_out, int n, int hw, int c, void* stream);
+int tg_gmaxpool_bwd_f32(const float* dfeat, int ld_d, const float* x, int ld_x, float* dx, int ld_dx, int n, int hw, int c, void* stream);
+/* out[n,:] = [mean_p x[n,p,:c], y[n,:ncls], 0...]: average_pooling2d(8) + squeeze + concat (Good_GAN_cifar10.py:94-96). */
+int tg_gavgpool_concat_f32(const float* x, int ld_x, int c, const float* y, int ncls, float* out, int ld_out, int n, int hw, void* stream);
+int tg_gavgpool_bwd_f32(const float* dfeat, int ld_d, const float* yact, int ld_y, float* out, int ld_out, int n, int hw, int c, int act,
+                        float alpha, void* stream);
+int tg_copy2d_f32(const float* src, int64_t ld_s, float* dst, int64_t ld_d, int64_t rows, int64_t c, void* stream);
+int tg_fill_f32(float* dst, float value, int64_t n, void* stream);
+/* tf.one_hot(tf.argmax(logits,1)) (Good_GAN_cifar10.py:232,237,259,270); out [n][k]. */
+int tg_argmax_onehot_f32(const float* logits, int ld, int n, int k, float* out, void* stream);
+
+/* ---- loss heads: value + d/dlogits in one launch (Training/train_base.py:113-154) ---------------- */
+/* rows [real | fake | unl]: d_loss = BCE(real,1) + .5 BCE(fake,0) + .5 BCE(unl,0). */
+int tg_d_loss_f32(const float* logits, int ld, int n_real, int n_fake, int n_unl, float* dlogits, int ld_d, float* loss, void* stream);
+/* g_loss = .5 BCE(D_fake,1). */
+int tg_g_loss_f32(const float* logits, int ld, int n, float* dlogits, int ld_d, float* loss, void* stream);
+/* rows [real | unl | unl_rep | fake] (n_rep = n_unl, or 0 when there is no consistency term); lambdas = device {l1,l2}:
+ * c_loss = .005 c_unl + CE(real) + 1e-6 H(unl) + 1e-3 Bal(unl) + l1 CE(fake) + l2 MSE(unl,rep). */
+int tg_c_loss_f32(const float* c_logits, int ld, int n_real, int n_unl, int n_rep, int n_fake, const float* y_real, const float* y_fake,
+                  const float* d_unl_logits, int ld_dunl, const float* lambdas, float* dlogits, int ld_d, float* loss, void* stream);
+/* feature matching (train_base.py:172) and pull-away (masked :175-181, unmasked :204-207) terms; dense [n][c] features. */
+int tg_feature_match_f32(const float* f_fake, int n_fake, const float* f_unl, int n_unl, int c, float* df_fake, float* df_unl, float* loss,
+                         void* stream);
+int tg_pull_away_f32(const float* f, int n, int c, int masked, float* scratch /* n*c+n*n+n floats */, float* df, float* loss, void* stream);
+/* counters[0] += #correct, counters[1] += n (tf.metrics.accuracy, Training/Train_goodGAN.py:428-447). */
+int tg_accuracy_count_f32(const float* logits, int ld, const float* labels, int n, int k, float* counters, void* stream);
+
+/* ---- optimiser ------------------------------------------------------------------------------------ */
+/* TF-form Adam over a flat buffer (Training/train_base.py:91-97); *step_dev is incremented first, lr read from device;
+ * g is multiplied by grad_scale (1/world_size after a sum all-reduce). */
+int tg_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2, float eps, int* step_dev,
+                float grad_scale, void* stream);
+/* shadow -= (1-decay)*(shadow - p) (tf.train.ExponentialMovingAverage, Training/Train_goodGAN.py:101-103). */
+int tg_ema_f32(float* shadow, const float* p, int64_t n, float decay, void* stream);
+
+/* ---- RNG (Philox4x32-10; state = device {seed, step}) -------------------------------------------- */
+int tg_rng_uniform_f32(float* out, int64_t n, float lo, float hi, const uint64_t* state, uint32_t stream_id, void* stream);
+int tg_rng_keep_mask_f32(float* out, int64_t n, float keep_prob, const uint64_t* state, uint32_t stream_id, void* stream);
+int tg_rng_normal_f32(float* out, int64_t n, float stddev, const uint64_t* state, uint32_t stream_id, void* stream);
+int tg_rng_onehot_f32(float* out, int rows, int k, const uint64_t* state, uint32_t stream_id, void* stream);
+int tg_rng_advance(uint64_t* state, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,113 @@
+"""NN_Base — MI355X-native counterpart of the reference's Model/modle_base.py (sic; the reference's
+models import it as `model_base`, Model/Good_GAN.py:8 — both spellings are provided here).
+
+Method names and arguments follow Model/modle_base.py:27-48 (_linear_fc), :157-168 (_conv2d),
+:190-202 (_drop_out, _add_noise), :229-237 (_batch_norm_contrib), :239-244 (_conv_cond_concat),
+:246-259 (_deconv2d).  Tensors are tg.runtime.Act handles; variables are looked up in the active
+Context under the names TF would create ('<scope>/<name>/<name>/kernel' for tf.layers.* called
+inside `with tf.variable_scope(name)` with `name=name`).
+
+Extensions (keyword-only, default = reference behaviour): `activation` fuses the nonlinearity the
+model applies next into the MFMA kernel's epilogue; `narrow` stores only the logical channels.
+Initialisers are applied when the Model creates its variables (see Good_GAN_cifar10.param_specs),
+so `kernel_initializer` is accepted and ignored here.
+"""
+from tg import ops
+from tg.runtime import ctx, Act
+
+
+def _act_of(fn):
+    if fn is None:
+        return None, 0.2
+    a = getattr(fn, 'tg_act', None)
+    if a is None:
+        raise ValueError("activation must be a tg activation (leakyReLu, tf-like relu/tanh helpers)")
+    return a
+
+
+class NN_Base(object):
+    def __init__(self, batch_norm_decay=0.9, batch_norm_epsilon=1e-5):
+        self._batch_norm_decay = batch_norm_decay
+        self._batch_norm_epsilon = batch_norm_epsilon
+
+    def forward_pass(self, x):
+        raise NotImplementedError('forward_pass() is implemented in Model sub classes')
+
+    # ---- activations usable as `activation=` / `nonlinearity=` ------------------------------------
+    def _relu(self, x):
+        raise NotImplementedError("standalone relu is always fused: pass activation=self._relu")
+    _relu.tg_act = ('relu', 0.0)
+
+    def _tanh(self, x):
+        raise NotImplementedError("standalone tanh is always fused: pass activation=self._tanh")
+    _tanh.tg_act = ('tanh', 0.0)
+
+    # ---- layers -----------------------------------------------------------------------------------
+    def _linear_fc(self, input_, output_size, scope=None, bias_start=0.0, use_bias=True, kernel_initializer=None,
+                   activation=None, narrow=False):
+        """tf.layers.dense + bias (Model/modle_base.py:27-48); runs as a 1-tap MFMA implicit GEMM."""
+        cx = ctx()
+        act, alpha = _act_of(activation)
+        with cx.variable_scope(scope), cx.variable_scope(scope):
+            tr = cx.trains()
+            return ops.conv2d(input_, cx.var('kernel'), cx.var('bias') if use_bias else None, output_size, 1, 1, 'SAME',
+                              act=act, alpha=alpha, kernel_grad=cx.var_grad('kernel') if tr else None,
+                              bias_grad=cx.var_grad('bias') if (tr and use_bias) else None,
+                              n_store_ld=(output_size, output_size) if narrow else None)
+
+    def _conv2d(self, input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, kernel_initializer=None, name="conv2d",
+                activation=None):
+        """tf.layers.conv2d 'same' + bias (Model/modle_base.py:157-168)."""
+        assert k_h == k_w and d_h == d_w
+        cx = ctx()
+        act, alpha = _act_of(activation)
+        with cx.variable_scope(name), cx.variable_scope(name):
+            tr = cx.trains()
+            return ops.conv2d(input_, cx.var('kernel'), cx.var('bias'), output_dim, k_h, d_h, 'SAME', act=act, alpha=alpha,
+                              kernel_grad=cx.var_grad('kernel') if tr else None, bias_grad=cx.var_grad('bias') if tr else None)
+
+    def _deconv2d(self, input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, name="deconv2d", use_bias=True,
+                  kernel_initializer=None, activation=None, narrow=False):
+        """tf.layers.conv2d_transpose 'same' + bias (Model/modle_base.py:246-259); output_shape = channels."""
+        assert (k_h, k_w, d_h, d_w) == (5, 5, 2, 2) and use_bias
+        cx = ctx()
+        act, _ = _act_of(activation)
+        with cx.variable_scope(name), cx.variable_scope(name):
+            tr = cx.trains()
+            return ops.deconv2d(input_, cx.var('kernel'), cx.var('bias'), output_shape, act=act,
+                                kernel_grad=cx.var_grad('kernel') if tr else None, bias_grad=cx.var_grad('bias') if tr else None,
+                                narrow_out=narrow)
+
+    def _batch_norm_contrib(self, x, name, train=False):
+        """tf.contrib.layers.batch_norm(decay, eps, scale=True, updates_collections=None) (modle_base.py:229-237).
+        Only the training branch is ever executed by the reference's models."""
+        if not train:
+            raise NotImplementedError("inference-mode batch norm is never executed by the reference's generator")
+        cx = ctx()
+        with cx.variable_scope(name):
+            tr = cx.trains()
+            return ops.batch_norm_train(x, cx.var('gamma'), cx.var('beta'), cx.var('moving_mean'), cx.var('moving_variance'),
+                                        self._batch_norm_epsilon, self._batch_norm_decay,
+                                        gamma_grad=cx.var_grad('gamma') if tr else None, beta_grad=cx.var_grad('beta') if tr else None)
+
+    def _conv_cond_concat(self, x, y):
+        """Concatenate conditioning vector on feature map axis (modle_base.py:239-244); y: Act [N,ncls]."""
+        return ops.cond_concat(x, y.t, y.c)
+
+    def _drop_out(self, x, rate=0.5, train=False):
+        """tf.layers.dropout (modle_base.py:190-191): x*mask/keep with a floor(keep+U) keep-mask."""
+        if not train:
+            return x
+        cx = ctx()
+        mask = cx.rng.keep_mask(cx, cx.next_rng_name('drop'), x.rows * x.c, 1.0 - rate)
+        assert x.ld == x.c
+        return ops.scale_mask(x, mask, 1.0 / (1.0 - rate))
+
+    def _add_noise(self, inputs, mean=0.0, stddev=0.001, ld_out=None):
+        """inputs + N(mean, stddev) (modle_base.py:193-202); output channel-padded for the next conv."""
+        assert mean == 0.0
+        cx = ctx()
+        noise = cx.rng.normal(cx, 'noise', inputs.rows * inputs.c, stddev)
+        assert inputs.ld == inputs.c
+        from tg.runtime import pad32
+        return ops.pad_add(inputs, noise, pad32(inputs.c) if ld_out is None else ld_out)

@@ -1,0 +1,305 @@
+"""Train — the Triple-GAN training driver, counterpart of the reference's Training/Train_goodGAN.py.
+
+Same entry point: `Train(config, log_dir, save_dir, **kwargs).train(Dataset, Model, sample_y)`
+(Train_goodGAN.py:27,43) and the same iteration protocol (:230-278):
+
+    D-update  (sess.run([d_solver, d_loss]))   G fwd, C(x_u_c), C(x_u_d) fwd, D x3 fwd, D bwd, Adam(D)
+    G-update  (sess.run([g_solver, g_loss]))   G fwd, D(G) fwd, D data-bwd, G bwd, Adam(G)
+    C-update  (sess.run([c_solver, c_loss]))   G fwd, C x4 fwd, D(x_u_c) fwd, C bwd, Adam(C), EMA(C)
+
+Each solver run executes only the sub-graph its fetches need and re-samples dropout / noise, exactly as three
+TF session calls on one feed do.  Instead of a TF graph + Session the three runs are captured
+once into hipGraphs and replayed (config.USE_HIP_GRAPH); hyper-parameters that change (lr, lambdas, Adam step,
+RNG step) live in device memory.  Applications of one network inside a solver run are batched into one call
+(D: [D_real|D_fake|D_unl] = 250 images; C: [C_real|C_unl|C_unl_rep|C_fake] = 250 images, mean-only-BN per
+application).  Data-parallel replicas (one process per GPU) sum-all-reduce the trained network's flat gradient
+buffer over RCCL after each backward (tg/dist.py); the reference has no multi-device path.
+"""
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+from Training.train_base import Train_base
+from tg import dist as tgdist
+from tg import lib, ops
+from tg.batching import concat_acts
+from tg.runtime import Act, Context, InjectedRNG, PhiloxRNG, ctx, set_context
+
+
+class Train(Train_base):
+    def __init__(self, config, log_dir, save_dir, **kwargs):
+        super(Train, self).__init__()
+        self.config = config
+        self.save_dir = save_dir
+        self.log_dir = log_dir
+        self.comments = kwargs.get('comments', '')
+        self.world, self.rank, self.local_rank = tgdist.init()
+        try:
+            self.cx = ctx()
+        except lib.TgError:
+            self.cx = set_context(Context('cuda:%d' % self.local_rank, seed=getattr(config, 'SEED', 0) + 7919 * self.rank))
+        cx = self.cx
+        # device-resident hyper-parameters (the reference's lr_ph / cla_lr_ph / lambda placeholders, :30-31,416-420)
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=cx.device)       # lr, cla_lr, lambda_1, lambda_2
+        self.loss_dev = torch.zeros(3, dtype=torch.float32, device=cx.device)    # d_loss, g_loss, c_loss
+        self.model = None
+        self._graphs = None
+        self._warm = False
+        self.iteration = 0
+
+    # ------------------------------------------------------------------ graph build
+    def _build_train_graph(self, Model):
+        """:400-426: the placeholders become persistent device buffers of the static batch sizes."""
+        c, cx = self.config, self.cx
+        dims = c.IMAGE_DIM
+
+        def ph(key, n, shape):
+            t = cx.ws('ph:' + key, n * int(np.prod(shape)))
+            return Act(t, n, *(shape if len(shape) == 3 else (1, 1, shape[0])), ld=shape[-1])
+
+        self.z_g_ph = ph('z_g', c.BATCH_SIZE_G, [c.Z_DIM])
+        self.y_g_ph = ph('y_g', c.BATCH_SIZE_G, [c.NUM_CLASSES])
+        self.x_l_c_ph = ph('x_l_c', c.BATCH_SIZE_L_C, dims)
+        self.y_l_c_ph = ph('y_l_c', c.BATCH_SIZE_L_C, [c.NUM_CLASSES])
+        self.x_l_d_ph = ph('x_l_d', c.BATCH_SIZE_L_D, dims)
+        self.y_l_d_ph = ph('y_l_d', c.BATCH_SIZE_L_D, [c.NUM_CLASSES])
+        self.x_u_d_ph = ph('x_u_d', c.BATCH_SIZE_U_D, dims)
+        self.x_u_c_ph = ph('x_u_c', c.BATCH_SIZE_U_C, dims)
+        self.model = Model(c)
+        st = cx.stores
+        # three Adam optimisers (:85-87): G and D share lr_ph / config.BETA1, C uses cla_lr_ph / 0.5
+        self.d_optimizer = self._Adam_optimizer(self.hyper[0:1], c.BETA1)
+        self.g_optimizer = self._Adam_optimizer(self.hyper[0:1], c.BETA1)
+        self.c_optimizer = self._Adam_optimizer(self.hyper[1:2], 0.5)
+        self.set_hyper(c.LEARNING_RATE, getattr(c, 'CLA_LEARNINIG_RATE', c.LEARNING_RATE), 0.0, 0.0)
+        if self.world > 1:                       # identical initial weights on every replica
+            for s in st.values():
+                tgdist.broadcast_(s.p)
+                tgdist.broadcast_(s.s)
+            st['classifier'].ema.copy_(st['classifier'].p)
+        PH = [self.z_g_ph, self.y_g_ph, self.x_l_c_ph, self.y_l_c_ph, self.x_l_d_ph, self.y_l_d_ph, self.x_u_d_ph,
+              self.x_u_c_ph, True, self.hyper[2:4]]
+        return PH, self.model
+
+    def set_hyper(self, lr=None, cla_lr=None, lambda_1=None, lambda_2=None):
+        vals = self.hyper.detach().cpu().numpy()
+        for i, v in enumerate((lr, cla_lr, lambda_1, lambda_2)):
+            if v is not None:
+                vals[i] = v
+        self.hyper.copy_(torch.from_numpy(vals))
+
+    # ------------------------------------------------------------------ the three solver runs
+    def _d_forward_backward(self):
+        c, cx, m = self.config, self.cx, self.model
+        with cx.phase_scope('D', train_nets=('discriminator',)):
+            G = m.good_generator(self.z_g_ph, self.y_g_ph)
+            xz = m.zca().apply(concat_acts([self.x_u_c_ph, self.x_u_d_ph])) if c.DATA_NAME == 'cifar10' else \
+                concat_acts([self.x_u_c_ph, self.x_u_d_ph])
+            with cx.rng_scoped('D/C'):
+                c_logits, _ = m.classifier(xz, True, segments=[c.BATCH_SIZE_U_C, c.BATCH_SIZE_U_D])
+            oh = ops.argmax_onehot(c_logits, c.NUM_CLASSES)                       # [C_unl_hard | C_unl_d_hard]
+            k = c.NUM_CLASSES
+            oh_unl = Act(oh[:c.BATCH_SIZE_U_C * k], c.BATCH_SIZE_U_C, 1, 1, k, k)
+            oh_unl_d = Act(oh[c.BATCH_SIZE_U_C * k:], c.BATCH_SIZE_U_D, 1, 1, k, k)
+            ximg = concat_acts([self.x_l_d_ph, self.x_u_d_ph, G, self.x_u_c_ph])  # X_P | G | x_u_c   (:258-271)
+            yall = concat_acts([self.y_l_d_ph, oh_unl_d, self.y_g_ph, oh_unl])
+            with cx.rng_scoped('D/D'):
+                _, d_logits = m.discriminator(ximg, yall)
+            self._d_loss(d_logits, c.BATCH_SIZE_L_D + c.BATCH_SIZE_U_D, c.BATCH_SIZE_G, c.BATCH_SIZE_U_C, self.loss_dev[0:1])
+            cx.backward()
+
+    def _g_forward_backward(self):
+        cx, m = self.cx, self.model
+        with cx.phase_scope('G', train_nets=('good_generator',)):
+            G = m.good_generator(self.z_g_ph, self.y_g_ph)
+            with cx.rng_scoped('G/D'):
+                _, d_fake = m.discriminator(G, self.y_g_ph)
+            self._g_loss(d_fake, self.loss_dev[1:2])
+            cx.backward()
+
+    def _c_forward_backward(self):
+        c, cx, m = self.config, self.cx, self.model
+        cifar = c.DATA_NAME == 'cifar10'
+        with cx.phase_scope('C', train_nets=('classifier',)):
+            G = m.good_generator(self.z_g_ph, self.y_g_ph)
+            parts = [self.x_l_c_ph, self.x_u_c_ph] + ([self.x_u_c_ph] if cifar else []) + [G]
+            segs = [p.n for p in parts]
+            xc = concat_acts(parts)
+            if cifar:
+                xc = m.zca().apply(xc)
+            with cx.rng_scoped('C/C'):
+                c_logits, _ = m.classifier(xc, True, segments=segs)
+            c_unl = c_logits.view_rows(segs[0], segs[0] + segs[1])
+            k = c.NUM_CLASSES
+            oh_unl = Act(ops.argmax_onehot(c_unl, k), c_unl.n, 1, 1, k, k)
+            with cx.rng_scoped('C/D'):
+                _, d_unl = m.discriminator(self.x_u_c_ph, oh_unl)
+            self._c_loss(c_logits, segs[0], segs[1], segs[1] if cifar else 0, G.n, self.y_l_c_ph, self.y_g_ph, d_unl,
+                         self.hyper[2:4], self.loss_dev[2:3])
+            cx.backward()
+
+    def _c_apply(self):
+        st = self.cx.stores['classifier']
+        self._train_op(self.c_optimizer, st, 1.0 / self.world)
+        # ema.apply(c_vars) under control-dependency on the C step (:101-103)
+        lib.call('tg_ema_f32', lib.ptr(st.ema), lib.ptr(st.p), st.n_p, 0.9999, self.cx.stream)
+        self.cx.rng.advance(self.cx)
+
+    def _segments(self, pre_train=False):
+        st = self.cx.stores
+        w = 1.0 / self.world
+        if pre_train:                                      # :182-226 only c_solver runs
+            return [(self._c_forward_backward, st['classifier']), (self._c_apply, None)]
+        return [
+            (self._d_forward_backward, st['discriminator']),
+            (lambda: (self._train_op(self.d_optimizer, st['discriminator'], w), self._g_forward_backward()), st['good_generator']),
+            (lambda: (self._train_op(self.g_optimizer, st['good_generator'], w), self._c_forward_backward()), st['classifier']),
+            (self._c_apply, None),
+        ]
+
+    # ------------------------------------------------------------------ one iteration
+    def feed(self, batch):
+        """host feed_dict (:249-263) -> placeholders.  batch keys: z_g,y_g,x_l_c,y_l_c,x_l_d,y_l_d,x_u_d,x_u_c
+        (numpy arrays or device Acts)."""
+        for key, ph in (('z_g', self.z_g_ph), ('y_g', self.y_g_ph), ('x_l_c', self.x_l_c_ph), ('y_l_c', self.y_l_c_ph),
+                        ('x_l_d', self.x_l_d_ph), ('y_l_d', self.y_l_d_ph), ('x_u_d', self.x_u_d_ph), ('x_u_c', self.x_u_c_ph)):
+            if key not in batch:
+                continue
+            v = batch[key]
+            if isinstance(v, Act):
+                ops.copy_rows(ph.t, 0, v.t, ph.t.numel())
+            else:
+                a = np.ascontiguousarray(v, np.float32).reshape(-1)
+                assert a.size == ph.t.numel(), (key, a.size, ph.t.numel())
+                ph.t.copy_(torch.from_numpy(a), non_blocking=False)
+
+    def sample_latent(self):
+        """z ~ U(-1,1), y ~ onehot(U{0..9}) (:234-239) drawn on the device."""
+        cx = self.cx
+        with cx.rng_scoped('latent'):
+            cx.rng.uniform(cx, 'z', self.z_g_ph.t.numel(), -1.0, 1.0, out=self.z_g_ph.t)
+            cx.rng.onehot(cx, 'y', self.y_g_ph.n, self.config.NUM_CLASSES, out=self.y_g_ph.t)
+
+    def train_iteration(self, pre_train=False, use_graph=None):
+        """D-update, G-update, C-update on the current placeholder contents (:266-276).  No host sync."""
+        cx = self.cx
+        use_graph = getattr(self.config, 'USE_HIP_GRAPH', True) if use_graph is None else use_graph
+        use_graph = use_graph and isinstance(cx.rng, PhiloxRNG)
+        segs = self._segments(pre_train)
+        key = 'pre' if pre_train else 'full'
+        if self._graphs is None:
+            self._graphs = {}
+        graphs = self._graphs.setdefault(key, [None] * len(segs))
+        for i, (fn, store) in enumerate(segs):
+            if use_graph and self._warm:
+                if graphs[i] is None:
+                    import ctypes as C
+                    lib.call('tg_graph_begin_capture', cx.stream)
+                    try:
+                        fn()
+                    finally:
+                        h = C.c_void_p()
+                        lib.call('tg_graph_end_capture', cx.stream, C.byref(h))
+                    graphs[i] = h
+                lib.call('tg_graph_launch', graphs[i], cx.stream)
+            else:
+                fn()
+            if store is not None and self.world > 1:
+                tgdist.allreduce_sum_(store.g)
+        self._warm = True
+        self.iteration += 1
+
+    def losses(self):
+        """(d_loss, g_loss, c_loss) of the last iteration — a device->host sync; call sparingly."""
+        return tuple(float(v) for v in self.loss_dev.detach().cpu().numpy())
+
+    # ------------------------------------------------------------------ evaluation
+    def evaluate(self, batches):
+        """streaming accuracy of argmax C_real_logits vs argmax y over test batches with train=False (:295-351, :428-447).
+        batches: iterable of (x [n,h,w,c], y onehot [n,k]) host arrays.  Returns accuracy."""
+        c, cx, m = self.config, self.cx, self.model
+        counters = torch.zeros(2, dtype=torch.float32, device=cx.device)
+        for x, y in batches:
+            with cx.phase_scope('val', record=False):
+                xa = cx.from_numpy(x, key='val:x')
+                ya = cx.from_numpy(y, key='val:y')
+                if c.DATA_NAME == 'cifar10':
+                    xa = m.zca().apply(xa)
+                with cx.rng_scoped('val/C'):
+                    logits, _ = m.classifier(xa, False)
+                lib.call('tg_accuracy_count_f32', logits.ptr, logits.ld, ya.ptr, logits.n, c.NUM_CLASSES, lib.ptr(counters), cx.stream)
+        correct, total = counters.cpu().numpy()
+        return float(correct) / max(float(total), 1.0)
+
+    def sample(self, sample_z, sample_y):
+        """model.good_sampler on fixed latents (:68,353-364) -> host array [N,H,W,C] in [-1,1]."""
+        cx = self.cx
+        with cx.phase_scope('sample', record=False):
+            out = self.model.good_sampler(cx.from_numpy(sample_z, key='smp:z'), cx.from_numpy(sample_y, key='smp:y'))
+            return out.numpy()
+
+    # ------------------------------------------------------------------ the reference's entry point
+    def train(self, Dataset, Model, sample_y):
+        """:43-381.  Dataset(data_dir, config, num_label, subset, use_augmentation).inputpipline_train_val(val)
+        -> (init_op_train, init_op_val, NNIO); NNIO.next() yields the feed of one iteration, NNIO.val_batches()
+        the test split."""
+        c = self.config
+        dataset_train = Dataset(c.DATA_DIR, c, c.NUM_LABEL, 'train', True)
+        dataset_val = Dataset(c.DATA_DIR, c, c.NUM_LABEL, 'test', False)
+        init_op_train, init_op_val, NNIO = dataset_train.inputpipline_train_val(dataset_val)
+        self._build_train_graph(Model)
+        sample_z = np.random.uniform(low=-1.0, high=1.0, size=(c.SAMPLE_SIZE, c.Z_DIM)).astype(np.float32)   # :130
+        lr, cla_lr = c.LEARNING_RATE, getattr(c, 'CLA_LEARNINIG_RATE', c.LEARNING_RATE)
+        start_epoch = 0
+        history = []
+        iters = int(c.TRAIN_SIZE / c.BATCH_SIZE)
+        for epoch in range(1, c.EPOCHS + 1):
+            lambda_1 = c.FAKE_G_LAMBDA if (start_epoch + epoch) > 200 else 0.          # :165
+            lambda_2 = (0.5 if epoch > 67 else 0.) if c.DATA_NAME == 'cifar10' else 0.  # :171
+            if start_epoch + epoch >= 300:                                             # :175-177
+                lr, cla_lr = lr * 0.995, cla_lr * 0.99
+            self.set_hyper(lr, cla_lr, lambda_1, lambda_2)
+            init_op_train()
+            pre = bool(c.PRE_TRAIN and (start_epoch + epoch <= 30))                    # :182
+            t0 = time.time()
+            for i in range(iters):
+                self.feed(NNIO.next())
+                self.sample_latent()
+                self.train_iteration(pre_train=pre)
+            d_loss, g_loss, c_loss = self.losses()
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            init_op_val()
+            acc = self.evaluate(NNIO.val_batches())
+            rec = dict(epoch=epoch + start_epoch, d_loss=d_loss, g_loss=g_loss, c_loss=c_loss, val_accuracy=acc,
+                       images_per_sec=iters * c.BATCH_SIZE * self.world / dt)
+            history.append(rec)
+            if self.rank == 0:
+                print("epoch {epoch}: g_loss {g_loss:.3f} d_loss {d_loss:.3f} c_loss {c_loss:.3f} val_acc {val_accuracy:.4f} "
+                      "{images_per_sec:.0f} img/s".format(**rec), flush=True)
+                if c.SAMPLE_DIR and sample_y is not None:
+                    from utils import save_images, image_manifold_size
+                    os.makedirs(c.SAMPLE_DIR, exist_ok=True)
+                    samples = self.sample(sample_z, sample_y)
+                    save_images(samples, image_manifold_size(samples.shape[0]),
+                                os.path.join(c.SAMPLE_DIR, 'train_{:02d}.png'.format(epoch + start_epoch)))   # :359-363
+        return history
+
+
+def rampup(epoch):
+    """:456-462 (unused by the reference's loop; kept for API parity)."""
+    if epoch < 300:
+        p = 1.0 - max(0.0, float(epoch)) / float(300)
+        return math.exp(-p * p * 5.0)
+    return 1.0
+
+
+def rampdown(epoch):
+    """:464-469."""
+    if epoch >= (300 - 50):
+        ep = (epoch - (300 - 50)) * 0.5
+        return math.exp(-(ep * ep) / 50)
+    return 1.0

@@ -1,0 +1,75 @@
+"""Base configuration class — same attribute names as the reference's config.py:9-93
+(including its spellings, e.g. CLA_LEARNINIG_RATE is set by the experiment configs)."""
+
+
+class Config(object):
+    NAME = None
+    ## Input pipeline
+    DATA_NAME = None
+    DATA_DIR = None
+    NUM_LABEL = None
+    BATCH_SIZE = None
+    BATCH_SIZE_L_D = None
+    SAMPLE_SIZE = 64
+
+    IMAGE_HEIGHT = None
+    IMAGE_WIDTH = None
+    CHANNEL = None
+    REPEAT = None
+
+    ## Model architecture
+    Z_DIM = None
+    NUM_CLASSES = None
+    MINIBATCH_DIS = False
+
+    ## Training settings
+    RESTORE = False
+    RUN = None
+    RESTORE_EPOCH = None
+    BATCH_NORM_DECAY = 0.9
+    BATCH_NORM_EPSILON = 1e-5
+    LEARNING_RATE = 3e-4
+    BETA1 = 0.5
+
+    PRE_TRAIN = False
+    EPOCHS = None
+    TRAIN_SIZE = None
+    VAL_STEP = None
+    SAVE_PER_EPOCH = 1
+    SUMMARY = True
+    SUMMARY_GRAPH = True
+    SUMMARY_SCALAR = True
+    SUMMARY_IMAGE = False
+    SUMMARY_HISTOGRAM = False
+
+    SAMPLE_DIR = None
+    LOG_DIR = None
+    WEIGHT_DIR = None
+    DEBUG = False
+
+    ## additions of the MI355X build (not in the reference)
+    SEED = 0                 # initial weights + Philox stream
+    USE_HIP_GRAPH = True     # replay the three solver runs as captured hipGraphs
+    ZCA = None               # (mean, mat) arrays when DATA_DIR holds no cifar10_zca_*.npy
+
+    def __init__(self):
+        """Set values of computed attributes (config.py:70-73)."""
+        self.MIN_QUEUE_EXAMPLES = self.BATCH_SIZE * 3
+        self.IMAGE_DIM = [self.IMAGE_HEIGHT, self.IMAGE_WIDTH, self.CHANNEL]
+
+    def display(self):
+        print("\nConfigurations:")
+        for a in dir(self):
+            if not a.startswith("__") and not callable(getattr(self, a)):
+                v = getattr(self, a)
+                print("{:30} {}".format(a, v if not isinstance(v, tuple) else '<arrays>'))
+        print("\n")
+
+    def config_str(self):
+        s = "\nConfigurations:\n"
+        for a in dir(self):
+            if not a.startswith("__") and not callable(getattr(self, a)):
+                v = getattr(self, a)
+                s += "{:30} {}".format(a, v if not isinstance(v, tuple) else '<arrays>')
+                s += "\n"
+        return s

@@ -1,0 +1,389 @@
+// HBM-bound statistics / normalisation kernels: per-(application segment, channel) column sums with a
+// deterministic two-stage reduction (wavefront-free of atomics), mean-only batch-norm and batch-norm
+// finalisers, and the fused shift/scale + activation passes (forward and backward).
+//
+// Access pattern: rows are NHWC pixels, channels contiguous; every lane moves 16 B (float4), a block's 32
+// column-groups cover 512 contiguous bytes per row, 8 rows in flight per pass.
+#include "tg_common.h"
+#include "tg_device.h"
+
+namespace {
+
+constexpr int RCH = 256;         // rows per stage-1 chunk
+constexpr int MAXSEG = 8;
+
+struct SegTable { int nseg; int rows[MAXSEG]; };
+
+__device__ __forceinline__ int seg_of_row(const SegTable& st, int r, int* row_in_seg_begin) {
+  int b = 0;
+  for (int s = 0; s < st.nseg; ++s) {
+    if (r < b + st.rows[s]) { *row_in_seg_begin = b; return s; }
+    b += st.rows[s];
+  }
+  *row_in_seg_begin = b;
+  return st.nseg - 1;
+}
+
+// mode: 0 SUM(a) ; 1 SUM(a), SUM(a^2) ; 2 SUM(a*act'(b)) ; 3 SUM(a), SUM(a*b)
+template <int MODE>
+__global__ void __launch_bounds__(256) colstats_stage1(const float* __restrict__ a, const float* __restrict__ b, int ld_a, int ld_b,
+                                                        int c4, SegTable st, int act, float alpha, float* __restrict__ part, int c_pad) {
+  // locate this block's chunk: (segment, row range)
+  int ch = blockIdx.y, seg = 0, base = 0;
+  for (; seg < st.nseg; ++seg) {
+    int n = (st.rows[seg] + RCH - 1) / RCH;
+    if (ch < n) break;
+    ch -= n;
+    base += st.rows[seg];
+  }
+  if (seg >= st.nseg) return;
+  const int r0 = base + ch * RCH;
+  const int r1 = min(base + st.rows[seg], r0 + RCH);
+  const int cg = blockIdx.x * 32 + (threadIdx.x & 31);   // float4 column group
+  const int ry = threadIdx.x >> 5;
+  float4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  if (cg < c4) {
+    for (int r = r0 + ry; r < r1; r += 8) {
+      float4 va = *reinterpret_cast<const float4*>(a + (int64_t)r * ld_a + cg * 4);
+      if (MODE == 0) {
+        s1.x += va.x; s1.y += va.y; s1.z += va.z; s1.w += va.w;
+      } else if (MODE == 1) {
+        s1.x += va.x; s1.y += va.y; s1.z += va.z; s1.w += va.w;
+        s2.x += va.x * va.x; s2.y += va.y * va.y; s2.z += va.z * va.z; s2.w += va.w * va.w;
+      } else {
+        float4 vb = *reinterpret_cast<const float4*>(b + (int64_t)r * ld_b + cg * 4);
+        if (MODE == 2) {
+          s1.x += va.x * tgd::act_grad(vb.x, act, alpha); s1.y += va.y * tgd::act_grad(vb.y, act, alpha);
+          s1.z += va.z * tgd::act_grad(vb.z, act, alpha); s1.w += va.w * tgd::act_grad(vb.w, act, alpha);
+        } else {
+          s1.x += va.x; s1.y += va.y; s1.z += va.z; s1.w += va.w;
+          s2.x += va.x * vb.x; s2.y += va.y * vb.y; s2.z += va.z * vb.z; s2.w += va.w * vb.w;
+        }
+      }
+    }
+  }
+  __shared__ float4 red[2][8][32];
+  red[0][ry][threadIdx.x & 31] = s1;
+  red[1][ry][threadIdx.x & 31] = s2;
+  __syncthreads();
+  if (ry == 0 && cg < c4) {
+    for (int k = 1; k < 8; ++k) {
+      float4 t1 = red[0][k][threadIdx.x & 31], t2 = red[1][k][threadIdx.x & 31];
+      s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
+      s2.x += t2.x; s2.y += t2.y; s2.z += t2.z; s2.w += t2.w;
+    }
+    float* o = part + ((int64_t)blockIdx.y * 2) * c_pad + cg * 4;
+    *reinterpret_cast<float4*>(o) = s1;
+    *reinterpret_cast<float4*>(o + c_pad) = s2;
+  }
+}
+
+__global__ void colstats_stage2(const float* __restrict__ part, SegTable st, int c_pad, int c, float* __restrict__ s1, float* __restrict__ s2) {
+  const int seg = blockIdx.y;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  int ch0 = 0;
+  for (int s = 0; s < seg; ++s) ch0 += (st.rows[s] + RCH - 1) / RCH;
+  const int n = (st.rows[seg] + RCH - 1) / RCH;
+  float a1 = 0.f, a2 = 0.f;
+  for (int k = 0; k < n; ++k) {
+    a1 += part[((int64_t)(ch0 + k) * 2) * c_pad + col];
+    a2 += part[((int64_t)(ch0 + k) * 2 + 1) * c_pad + col];
+  }
+  s1[seg * c + col] = a1;
+  if (s2) s2[seg * c + col] = a2;
+}
+
+// y[r][c] = act(x[r][c]*scale[c] + shift[seg(r)][c]) for c < C; zero for C <= c < c_zero_to.
+__global__ void __launch_bounds__(256) seg_scale_shift_act(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int rows, int c,
+                                                           int c_zero_to, SegTable st, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int act, float alpha) {
+  const int c4 = (c_zero_to + 3) / 4;
+  const int64_t total = (int64_t)rows * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c4), cg = (int)(i - (int64_t)r * c4);
+    int sb;
+    const int seg = seg_of_row(st, r, &sb);
+    float v[4];
+    float4 xv = {0, 0, 0, 0};
+    if (cg * 4 < c) xv = *reinterpret_cast<const float4*>(x + (int64_t)r * ld_x + cg * 4);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cc = cg * 4 + k;
+      float t = 0.f;
+      if (cc < c) {
+        t = xs[k];
+        if (scale) t *= scale[cc];
+        t = tgd::act(t + shift[seg * c + cc], act, alpha);
+      }
+      v[k] = t;
+    }
+    *reinterpret_cast<float4*>(y + (int64_t)r * ld_y + cg * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// dx[r][c] = dy[r][c]*act'(yact[r][c]) + shift[seg(r)][c]   (mean-only BN backward)
+__global__ void __launch_bounds__(256) seg_actgrad_shift(const float* __restrict__ dy, int ld_dy, const float* __restrict__ yact, int ld_y,
+                                                         float* __restrict__ dx, int ld_dx, int rows, int c, SegTable st,
+                                                         const float* __restrict__ shift, int act, float alpha) {
+  const int c4 = (c + 3) / 4;
+  const int64_t total = (int64_t)rows * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c4), cg = (int)(i - (int64_t)r * c4);
+    int sb;
+    const int seg = seg_of_row(st, r, &sb);
+    float4 g = *reinterpret_cast<const float4*>(dy + (int64_t)r * ld_dy + cg * 4);
+    float4 ya = *reinterpret_cast<const float4*>(yact + (int64_t)r * ld_y + cg * 4);
+    const float gs[4] = {g.x, g.y, g.z, g.w}, ys[4] = {ya.x, ya.y, ya.z, ya.w};
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cc = cg * 4 + k;
+      v[k] = cc < c ? gs[k] * tgd::act_grad(ys[k], act, alpha) + shift[seg * c + cc] : 0.f;
+    }
+    *reinterpret_cast<float4*>(dx + (int64_t)r * ld_dx + cg * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// dx = (A[c]*dy + B[c]*x + C[c]) * (x > 0)     (batch-norm backward through the preceding ReLU; x = relu output)
+__global__ void __launch_bounds__(256) bn_bwd_apply(const float* __restrict__ dy, int ld_dy, const float* __restrict__ x, int ld_x,
+                                                    float* __restrict__ dx, int ld_dx, int rows, int c, const float* __restrict__ abc,
+                                                    int relu_mask) {
+  const int c4 = (c + 3) / 4;
+  const int64_t total = (int64_t)rows * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c4), cg = (int)(i - (int64_t)r * c4);
+    float4 g = *reinterpret_cast<const float4*>(dy + (int64_t)r * ld_dy + cg * 4);
+    float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)r * ld_x + cg * 4);
+    const float gs[4] = {g.x, g.y, g.z, g.w}, xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cc = cg * 4 + k;
+      float t = 0.f;
+      if (cc < c) {
+        t = abc[cc] * gs[k] + abc[c + cc] * xs[k] + abc[2 * c + cc];
+        if (relu_mask && !(xs[k] > 0.f)) t = 0.f;
+      }
+      v[k] = t;
+    }
+    *reinterpret_cast<float4*>(dx + (int64_t)r * ld_dx + cg * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+__global__ void mobn_finalize(const float* __restrict__ sums, SegTable st, int c, const float* __restrict__ b, float* __restrict__ pop, float decay,
+                              int train, float* __restrict__ shift) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  float pm = pop[col];
+  const float bb = b ? b[col] : 0.f;
+  for (int s = 0; s < st.nseg; ++s) {
+    if (train) {
+      const float m = sums[s * c + col] / (float)st.rows[s];
+      shift[s * c + col] = bb - m;
+      pm = pm * decay + m * (1.f - decay);   // sequential pop_mean updates in call-site order (nn.py:181)
+    } else {
+      shift[s * c + col] = bb - pm;
+    }
+  }
+  if (train) pop[col] = pm;
+}
+
+__global__ void mobn_bwd_finalize(const float* __restrict__ sums, SegTable st, int c, float* __restrict__ shift, float* __restrict__ db) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  float tot = 0.f;
+  for (int s = 0; s < st.nseg; ++s) {
+    const float v = sums[s * c + col];
+    shift[s * c + col] = -v / (float)st.rows[s];
+    tot += v;
+  }
+  db[col] = tot;
+}
+
+__global__ void bn_finalize(const float* __restrict__ s1, const float* __restrict__ s2, int rows, int c, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                            float* __restrict__ mean_inv, float* __restrict__ mm, float* __restrict__ mv, float decay, int bessel) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  const float mu = s1[col] / (float)rows;
+  float var = s2[col] / (float)rows - mu * mu;   // biased
+  var = var > 0.f ? var : 0.f;
+  const float inv = 1.f / sqrtf(var + eps);
+  const float sc = gamma[col] * inv;
+  scale[col] = sc;
+  shift[col] = beta[col] - mu * sc;
+  mean_inv[col] = mu;
+  mean_inv[c + col] = inv;
+  if (mm) {   // moving statistics: dead state of G's always-training BN
+    const float v = bessel && rows > 1 ? var * ((float)rows / (float)(rows - 1)) : var;
+    mm[col] = mm[col] * decay + mu * (1.f - decay);
+    mv[col] = mv[col] * decay + v * (1.f - decay);
+  }
+}
+
+__global__ void bn_bwd_finalize(const float* __restrict__ s_dy, const float* __restrict__ s_dyx, int rows, int c, const float* __restrict__ gamma,
+                                const float* __restrict__ mean_inv, float* __restrict__ abc, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  const float mu = mean_inv[col], inv = mean_inv[c + col], g = gamma[col];
+  const float dbt = s_dy[col];
+  const float dgm = inv * (s_dyx[col] - mu * dbt);     // sum dy * xhat
+  dgamma[col] = dgm;
+  dbeta[col] = dbt;
+  const float m = (float)rows;
+  const float A = g * inv;
+  const float B = -g * inv * inv * dgm / m;
+  abc[col] = A;
+  abc[c + col] = B;
+  abc[2 * c + col] = -A * dbt / m - B * mu;
+}
+
+int make_segs(SegTable& st, const int32_t* seg_rows, int nseg, int rows) {
+  TG_REQUIRE(nseg >= 1 && nseg <= MAXSEG, "nseg=%d out of range", nseg);
+  int tot = 0;
+  st.nseg = nseg;
+  for (int i = 0; i < nseg; ++i) { st.rows[i] = seg_rows[i]; tot += seg_rows[i]; TG_REQUIRE(seg_rows[i] > 0, "empty segment %d", i); }
+  TG_REQUIRE(tot == rows, "segments sum to %d, rows=%d", tot, rows);
+  return TG_OK;
+}
+
+int num_chunks(const SegTable& st) {
+  int n = 0;
+  for (int i = 0; i < st.nseg; ++i) n += (st.rows[i] + RCH - 1) / RCH;
+  return n;
+}
+
+int ew_grid(int64_t work) {
+  int64_t b = (work + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t tg_colstats_workspace_floats(int rows, int nseg, int c) {
+  // upper bound: every segment adds at most one partial chunk
+  int c_pad = (c + 3) / 4 * 4;
+  return (int64_t)((rows + RCH - 1) / RCH + nseg) * 2 * c_pad;
+}
+
+int tg_colstats_f32(int mode, const float* a, int ld_a, const float* b, int ld_b, int rows, int c, const int32_t* seg_rows, int nseg,
+                    int act, float alpha, float* workspace, float* s1, float* s2, void* stream) {
+  SegTable st;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(a && workspace && s1, "colstats: null buffer");
+  TG_REQUIRE(ld_a % 4 == 0 && (b == nullptr || ld_b % 4 == 0), "colstats: ld must be a multiple of 4");
+  TG_REQUIRE((mode == 0 || mode == 1) || b != nullptr, "colstats: mode %d needs operand b", mode);
+  const int c4 = (c + 3) / 4, c_pad = c4 * 4;
+  TG_REQUIRE(c_pad <= ld_a && (b == nullptr || c_pad <= ld_b), "colstats: c=%d exceeds ld", c);
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 4.0 * rows * c * (b ? 2 : 1), s);
+  dim3 grid((c4 + 31) / 32, num_chunks(st));
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(colstats_stage1<0>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, workspace, c_pad); break;
+    case 1: hipLaunchKernelGGL(colstats_stage1<1>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, workspace, c_pad); break;
+    case 2: hipLaunchKernelGGL(colstats_stage1<2>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, workspace, c_pad); break;
+    case 3: hipLaunchKernelGGL(colstats_stage1<3>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, workspace, c_pad); break;
+    default: tg::set_error("colstats: bad mode %d", mode); return TG_ERR_INVALID;
+  }
+  TG_CHECK_LAUNCH("colstats_stage1");
+  hipLaunchKernelGGL(colstats_stage2, dim3((c + 127) / 128, nseg), dim3(128), 0, s, workspace, st, c_pad, c, s1, s2);
+  TG_CHECK_LAUNCH("colstats_stage2");
+  return TG_OK;
+}
+
+int tg_seg_scale_shift_act_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int c, int c_zero_to, const int32_t* seg_rows, int nseg,
+                               const float* scale, const float* shift, int act, float alpha, void* stream) {
+  SegTable st;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(x && y && shift, "seg_scale_shift_act: null buffer");
+  TG_REQUIRE(ld_x % 4 == 0 && ld_y % 4 == 0 && c_zero_to >= c && (c_zero_to + 3) / 4 * 4 <= ld_y && (c + 3) / 4 * 4 <= ld_x,
+             "seg_scale_shift_act: c=%d c_zero_to=%d ld_x=%d ld_y=%d", c, c_zero_to, ld_x, ld_y);
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 8.0 * rows * c, s);
+  hipLaunchKernelGGL(seg_scale_shift_act, dim3(ew_grid((int64_t)rows * ((c_zero_to + 3) / 4))), dim3(256), 0, s, x, ld_x, y, ld_y, rows, c,
+                     c_zero_to, st, scale, shift, act, alpha);
+  TG_CHECK_LAUNCH("seg_scale_shift_act");
+  return TG_OK;
+}
+
+int tg_seg_actgrad_shift_f32(const float* dy, int ld_dy, const float* yact, int ld_y, float* dx, int ld_dx, int rows, int c,
+                             const int32_t* seg_rows, int nseg, const float* shift, int act, float alpha, void* stream) {
+  SegTable st;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(dy && yact && dx && shift, "seg_actgrad_shift: null buffer");
+  const int cp = (c + 3) / 4 * 4;
+  TG_REQUIRE(ld_dy % 4 == 0 && ld_y % 4 == 0 && ld_dx % 4 == 0 && cp <= ld_dy && cp <= ld_y && cp <= ld_dx, "seg_actgrad_shift: c=%d vs ld", c);
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 12.0 * rows * c, s);
+  hipLaunchKernelGGL(seg_actgrad_shift, dim3(ew_grid((int64_t)rows * (cp / 4))), dim3(256), 0, s, dy, ld_dy, yact, ld_y, dx, ld_dx, rows, c, st,
+                     shift, act, alpha);
+  TG_CHECK_LAUNCH("seg_actgrad_shift");
+  return TG_OK;
+}
+
+int tg_bn_bwd_apply_f32(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const float* abc,
+                        int relu_mask, void* stream) {
+  TG_REQUIRE(dy && x && dx && abc, "bn_bwd_apply: null buffer");
+  const int cp = (c + 3) / 4 * 4;
+  TG_REQUIRE(ld_dy % 4 == 0 && ld_x % 4 == 0 && ld_dx % 4 == 0 && cp <= ld_dy && cp <= ld_x && cp <= ld_dx, "bn_bwd_apply: c=%d vs ld", c);
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 12.0 * rows * c, s);
+  hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid((int64_t)rows * (cp / 4))), dim3(256), 0, s, dy, ld_dy, x, ld_x, dx, ld_dx, rows, c, abc, relu_mask);
+  TG_CHECK_LAUNCH("bn_bwd_apply");
+  return TG_OK;
+}
+
+int tg_mobn_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, int rows, int c, const float* b, float* pop_mean, float decay,
+                         int train, float* shift, void* stream) {
+  SegTable st;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(pop_mean && shift && (sums || !train), "mobn_finalize: null buffer");
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 0, s);
+  hipLaunchKernelGGL(mobn_finalize, dim3((c + 127) / 128), dim3(128), 0, s, sums, st, c, b, pop_mean, decay, train, shift);
+  TG_CHECK_LAUNCH("mobn_finalize");
+  return TG_OK;
+}
+
+int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, int rows, int c, float* shift, float* db, void* stream) {
+  SegTable st;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(sums && shift && db, "mobn_bwd_finalize: null buffer");
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 0, s);
+  hipLaunchKernelGGL(mobn_bwd_finalize, dim3((c + 127) / 128), dim3(128), 0, s, sums, st, c, shift, db);
+  TG_CHECK_LAUNCH("mobn_bwd_finalize");
+  return TG_OK;
+}
+
+int tg_bn_finalize_f32(const float* s1, const float* s2, int rows, int c, const float* gamma, const float* beta, float eps, float* scale,
+                       float* shift, float* mean_inv, float* moving_mean, float* moving_var, float decay, int bessel, void* stream) {
+  TG_REQUIRE(s1 && s2 && gamma && beta && scale && shift && mean_inv, "bn_finalize: null buffer");
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 0, s);
+  hipLaunchKernelGGL(bn_finalize, dim3((c + 127) / 128), dim3(128), 0, s, s1, s2, rows, c, gamma, beta, eps, scale, shift, mean_inv, moving_mean,
+                     moving_var, decay, bessel);
+  TG_CHECK_LAUNCH("bn_finalize");
+  return TG_OK;
+}
+
+int tg_bn_bwd_finalize_f32(const float* s_dy, const float* s_dyx, int rows, int c, const float* gamma, const float* mean_inv, float* abc,
+                           float* dgamma, float* dbeta, void* stream) {
+  TG_REQUIRE(s_dy && s_dyx && gamma && mean_inv && abc && dgamma && dbeta, "bn_bwd_finalize: null buffer");
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 0, s);
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3((c + 127) / 128), dim3(128), 0, s, s_dy, s_dyx, rows, c, gamma, mean_inv, abc, dgamma, dbeta);
+  TG_CHECK_LAUNCH("bn_bwd_finalize");
+  return TG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,150 @@
+// Parameter-side kernels: weight-norm reparameterisation (forward + backward), filter re-layout with
+// channel padding for the MFMA kernels, and the deterministic split-K slab reduction of tg_wgrad_f32.
+// Column (= output channel) reductions keep 32 consecutive channels per wave row for 128-B coalesced
+// reads and finish with an LDS tree; the re-layout is a padded 32x32 LDS tile transpose.
+#include "tg_common.h"
+#include "tg_device.h"
+
+namespace {
+
+// scale[c] = g[c] * rsqrt(max(sum_r V[r][c]^2, 1e-12))        (tf.nn.l2_normalize, Model/nn.py:502)
+__global__ void __launch_bounds__(256) wn_scale(const float* __restrict__ v, const float* __restrict__ g, int r, int c, float* __restrict__ scale) {
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+  float acc = 0.f;
+  if (col < c)
+    for (int i = ry; i < r; i += 8) { const float t = v[(int64_t)i * c + col]; acc += t * t; }
+  __shared__ float red[8][32];
+  red[ry][threadIdx.x & 31] = acc;
+  __syncthreads();
+  if (ry == 0 && col < c) {
+    for (int k = 1; k < 8; ++k) acc += red[k][threadIdx.x & 31];
+    scale[col] = g[col] * rsqrtf(fmaxf(acc, 1e-12f));
+  }
+}
+
+// dg[c] = <dW[:,c], V[:,c]> / ||V[:,c]|| ;  coef[c] = {g/||V||, <dW,V>/||V||^2}
+__global__ void __launch_bounds__(256) wn_bwd_cols(const float* __restrict__ dw, const float* __restrict__ v, const float* __restrict__ g, int r, int c,
+                                                   float* __restrict__ dg, float* __restrict__ coef) {
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+  float dot = 0.f, ss = 0.f;
+  if (col < c)
+    for (int i = ry; i < r; i += 8) {
+      const float t = v[(int64_t)i * c + col];
+      dot += dw[(int64_t)i * c + col] * t;
+      ss += t * t;
+    }
+  __shared__ float red[2][8][32];
+  red[0][ry][threadIdx.x & 31] = dot;
+  red[1][ry][threadIdx.x & 31] = ss;
+  __syncthreads();
+  if (ry == 0 && col < c) {
+    for (int k = 1; k < 8; ++k) { dot += red[0][k][threadIdx.x & 31]; ss += red[1][k][threadIdx.x & 31]; }
+    const float nrm = sqrtf(ss);
+    dg[col] = dot / nrm;
+    coef[col] = g[col] / nrm;
+    coef[c + col] = dot / ss;
+  }
+}
+
+__global__ void __launch_bounds__(256) wn_bwd_apply(const float* __restrict__ dw, const float* __restrict__ v, const float* __restrict__ coef, int64_t n,
+                                                    int c, float* __restrict__ dv) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % c);
+    dv[i] = coef[col] * (dw[i] - v[i] * coef[c + col]);
+  }
+}
+
+// src [T][A][B] (B contiguous), optional per-b scale.
+//   dst_same[t][a][b]      padded copy  [T][A_pad][B_pad]
+//   dst_tr  [b*sb + t*st + a]           (a contiguous; rows b < B_pad, a < A_pad, zero padded)
+__global__ void __launch_bounds__(256) filter_prep(const float* __restrict__ src, const float* __restrict__ scale, int a_dim, int b_dim, int a_pad, int b_pad,
+                                                   float* __restrict__ dst_same, float* __restrict__ dst_tr, int64_t sb, int64_t st) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z, a0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int a = a0 + i, b = b0 + tx;
+    float v = 0.f;
+    if (a < a_dim && b < b_dim) {
+      v = src[((int64_t)t * a_dim + a) * b_dim + b];
+      if (scale) v *= scale[b];
+    }
+    tile[i][tx] = v;
+    if (dst_same && a < a_pad && b < b_pad) dst_same[((int64_t)t * a_pad + a) * b_pad + b] = v;
+  }
+  __syncthreads();
+  if (dst_tr) {
+    for (int i = ty; i < 32; i += 8) {
+      const int b = b0 + i, a = a0 + tx;
+      if (b < b_pad && a < a_pad) dst_tr[(int64_t)b * sb + (int64_t)t * st + a] = tile[tx][i];
+    }
+  }
+}
+
+// dst[t][c][n] = sum_s slab[s][t][c][n], c < C, n < N  (fixed summation order -> bitwise reproducible)
+__global__ void __launch_bounds__(256) slab_reduce(const float* __restrict__ slab, int n_split, int t_dim, int c_pad, int n_pad, int c_dim, int n_dim,
+                                                   float* __restrict__ dst) {
+  const int64_t total = (int64_t)t_dim * c_dim * n_dim;
+  const int64_t sstride = (int64_t)t_dim * c_pad * n_pad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % n_dim);
+    const int64_t tc = i / n_dim;
+    const int c = (int)(tc % c_dim), t = (int)(tc / c_dim);
+    const float* p = slab + ((int64_t)t * c_pad + c) * n_pad + n;
+    float acc = 0.f;
+    for (int s = 0; s < n_split; ++s) acc += p[s * sstride];
+    dst[i] = acc;
+  }
+}
+
+int ew_grid(int64_t work) {
+  int64_t b = (work + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_wn_scale_f32(const float* v, const float* g, int rows, int c, float* scale, void* stream) {
+  TG_REQUIRE(v && g && scale && rows > 0 && c > 0, "wn_scale: bad args");
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * rows * c, s);
+  hipLaunchKernelGGL(wn_scale, dim3((c + 31) / 32), dim3(256), 0, s, v, g, rows, c, scale);
+  TG_CHECK_LAUNCH("wn_scale");
+  return TG_OK;
+}
+
+int tg_filter_prep_f32(const float* src, const float* scale, int t, int a, int b, int a_pad, int b_pad, float* dst_same, float* dst_tr, int64_t tr_sb,
+                       int64_t tr_st, void* stream) {
+  TG_REQUIRE(src && (dst_same || dst_tr) && t > 0 && a > 0 && b > 0 && a_pad >= a && b_pad >= b, "filter_prep: bad args");
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * t * ((double)a * b + (double)a_pad * b_pad * ((dst_same ? 1 : 0) + (dst_tr ? 1 : 0))), s);
+  hipLaunchKernelGGL(filter_prep, dim3((a_pad + 31) / 32, (b_pad + 31) / 32, t), dim3(256), 0, s, src, scale, a, b, a_pad, b_pad, dst_same, dst_tr,
+                     tr_sb, tr_st);
+  TG_CHECK_LAUNCH("filter_prep");
+  return TG_OK;
+}
+
+int tg_slab_reduce_f32(const float* slab, int n_split, int t, int c_pad, int n_pad, int c, int n, float* dst, void* stream) {
+  TG_REQUIRE(slab && dst && n_split >= 1 && c <= c_pad && n <= n_pad, "slab_reduce: bad args");
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * t * c * n * (n_split + 1), s);
+  hipLaunchKernelGGL(slab_reduce, dim3(ew_grid((int64_t)t * c * n)), dim3(256), 0, s, slab, n_split, t, c_pad, n_pad, c, n, dst);
+  TG_CHECK_LAUNCH("slab_reduce");
+  return TG_OK;
+}
+
+/* coef: scratch of 2*c floats */
+int tg_wn_bwd_f32(const float* dw, const float* v, const float* g, int rows, int c, float* dv, float* dg, float* coef, void* stream) {
+  TG_REQUIRE(dw && v && g && dv && dg && coef, "wn_bwd: null buffer");
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * rows * c * 5, s);
+  hipLaunchKernelGGL(wn_bwd_cols, dim3((c + 31) / 32), dim3(256), 0, s, dw, v, g, rows, c, dg, coef);
+  TG_CHECK_LAUNCH("wn_bwd_cols");
+  hipLaunchKernelGGL(wn_bwd_apply, dim3(ew_grid((int64_t)rows * c)), dim3(256), 0, s, dw, v, coef, (int64_t)rows * c, c, dv);
+  TG_CHECK_LAUNCH("wn_bwd_apply");
+  return TG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL (backend 'nccl' on ROCm) or gloo (CPU
+tests).  The Triple-GAN step shards by image batch: every replica runs the three solver phases on
+its own batch and the three networks' flat gradient buffers are sum-all-reduced once per phase; Adam then applies
+grad/world_size identically on every replica, so weights stay bit-identical."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+
+
+def init(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  Returns (world, rank, local_rank)."""
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return world, rank, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def allreduce_sum_(flat):
+    """in-place sum over replicas of a flat gradient buffer (one collective per network per iteration)."""
+    if world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def allreduce_mean_(flat):
+    if world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world_size())
+    return flat
+
+
+def broadcast_(flat, src=0):
+    if world_size() > 1:
+        dist.broadcast(flat, src=src)
+    return flat
+
+
+def max_over_ranks(value, device):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()

@@ -2,6 +2,7 @@
 HIP library is missing or a call fails, the product path raises."""
 import ctypes as C
 import os
+import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libtg_hip.so")
@@ -26,31 +27,47 @@ class IgemmDesc(C.Structure):
     ]
 
 
-_P = C.c_void_p
-_I = C.c_int
-_L = C.c_int64
-_F = C.c_float
-_D = C.POINTER(IgemmDesc)
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "tg_kernels.h")
 
-# name -> argtypes (restype is int unless listed in _RESTYPES)
-SIGNATURES = {
-    "tg_version": [],
-    "tg_last_error_string": [],
-    "tg_device_count": [],
-    "tg_graph_begin_capture": [_P],
-    "tg_graph_end_capture": [_P, C.POINTER(_P)],
-    "tg_graph_launch": [_P, _P],
-    "tg_graph_destroy": [_P],
-    "tg_prof_enable": [_I],
-    "tg_prof_reset": [],
-    "tg_prof_num_classes": [],
-    "tg_prof_class_name": [_I],
-    "tg_prof_collect": [_I, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)],
-    "tg_igemm_f32": [_D, _P, _P, _P, _P, _P],
-    "tg_wgrad_f32": [_D, _P, _P, _P, _I, _P],
-}
-_RESTYPES = {"tg_last_error_string": C.c_char_p, "tg_prof_class_name": C.c_char_p}
-_NOCHECK = {"tg_version", "tg_last_error_string", "tg_device_count", "tg_prof_num_classes", "tg_prof_class_name"}
+_SCALARS = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint32_t": C.c_uint32, "float": C.c_float}
+_RET = {"int": C.c_int, "int64_t": C.c_int64, "const char*": C.c_char_p}
+_NOCHECK = {"tg_version", "tg_last_error_string", "tg_device_count", "tg_prof_num_classes", "tg_prof_class_name",
+            "tg_colstats_workspace_floats"}
+HOST_INT_ARRAYS = {"seg_rows"}          # pointer arguments that are HOST arrays
+
+
+def _ctype_of(decl):
+    decl = re.sub(r"/\*.*?\*/", "", decl).strip()
+    name = decl.split()[-1].lstrip("*")
+    typ = decl[: decl.rindex(name)].strip()
+    if typ.endswith("*"):
+        base = typ.replace("const", "").replace("*", "").strip()
+        if base == "tg_igemm_desc":
+            return C.POINTER(IgemmDesc)
+        if typ.count("*") == 2:
+            return C.POINTER(C.c_void_p)
+        if name in HOST_INT_ARRAYS:
+            return C.POINTER(C.c_int32)
+        if name in ("ms", "flops", "bytes"):
+            return C.POINTER(C.c_double)
+        if name == "launches":
+            return C.POINTER(C.c_int64)
+        return C.c_void_p
+    return _SCALARS[typ]
+
+
+def parse_header(path=HEADER_PATH):
+    """{symbol: (restype, [argtypes])} for every function include/tg_kernels.h declares."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = text[text.index('extern "C"'):]
+    out = {}
+    for m in re.finditer(r"(const char\*|int64_t|int)\s+(tg_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        argtypes = [] if args in ("void", "") else [_ctype_of(a) for a in args.split(",")]
+        out[name] = (_RET[ret], argtypes)
+    return out
+
 
 _lib = None
 
@@ -67,10 +84,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise TgError("HIP extension missing: %s (run __graft_entry__.build() / make -C csrc)" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
-    for name, argtypes in SIGNATURES.items():
+    for name, (restype, argtypes) in parse_header().items():
         fn = getattr(lib, name)          # AttributeError if the header and the .so drift apart
         fn.argtypes = argtypes
-        fn.restype = _RESTYPES.get(name, C.c_int)
+        fn.restype = restype
     _lib = lib
     return lib
 

@@ -1,0 +1,316 @@
+"""Kernel-level building blocks (forward + recorded backward) that Model/nn.py and
+Model/model_base.py compose.  Every function launches tg_* kernels through the C ABI on the
+context's stream and, when a tape is active, records a closure producing the input / variable
+gradients.  Gradient of an activation `a` lives in `a.grad` (an Act of identical layout)."""
+import ctypes as C
+
+from . import geom, lib
+from .lib import ACT
+from .runtime import Act, ctx, pad32, seg_array
+
+_call = lib.call
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _segs(x, segments):
+    """per-application image counts -> row counts of the batched activation."""
+    if segments is None:
+        segments = [x.n]
+    assert sum(segments) == x.n, (segments, x.n)
+    per = x.h * x.w
+    return [s * per for s in segments]
+
+
+# ------------------------------------------------------------------ statistics helpers
+
+def colstats(mode, a_t, ld_a, b_t, ld_b, rows, c, seg_rows, act=None, alpha=0.2, s1=None, s2=None):
+    cx = ctx()
+    nseg = len(seg_rows)
+    wsn = _call('tg_colstats_workspace_floats', rows, nseg, c)
+    work = cx.scratch('cs', wsn)
+    if s1 is None:
+        s1 = cx.scratch('s1_', nseg * c)
+    if s2 is None and mode in (1, 3):
+        s2 = cx.scratch('s2_', nseg * c)
+    _call('tg_colstats_f32', mode, _p(a_t), ld_a, _p(b_t), ld_b, rows, c, seg_array(seg_rows), nseg, ACT[act], alpha,
+          _p(work), _p(s1), _p(s2), cx.stream)
+    return s1, s2
+
+
+def wgrad_splits(desc, m):
+    ct = 128 if desc.ld_in % 128 == 0 else (64 if desc.ld_in % 64 == 0 else 32)
+    nt = 128 if desc.c_out % 128 == 0 else (64 if desc.c_out % 64 == 0 else 32)
+    tiles = desc.n_taps * (desc.ld_in // ct) * (desc.c_out // nt)
+    return max(1, min(-(-768 // tiles), m // 512))
+
+
+def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst):
+    """dst[t][c_dim][n_dim] = filter gradient via tg_wgrad_f32 slabs + deterministic reduce."""
+    cx = ctx()
+    m = desc.n_img * desc.h_v * desc.w_v
+    ns = wgrad_splits(desc, m)
+    slab = cx.scratch('slab', ns * t * desc.ld_in * desc.c_out)
+    _call('tg_wgrad_f32', desc, _p(in_act_t), _p(dout_t), _p(slab), ns, cx.stream)
+    _call('tg_slab_reduce_f32', _p(slab), ns, t, desc.ld_in, desc.c_out, c_dim, n_dim, _p(dst), cx.stream)
+
+
+# ------------------------------------------------------------------ conv / dense (plain and weight-normalised)
+
+def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=None, mobn=None, segments=None,
+           train=True, kernel_grad=None, bias_grad=None, n_store_ld=None):
+    """y = act(conv(x, W) + bias)   or, with wn=(g, g_grad) and mobn=(b, b_grad, pop_mean):
+       W = g V/||V||; y = act(conv(x, W) - mean_seg + b)            (Model/nn.py:469-520,525-589).
+    kernel: HWIO tensor [k,k,c_in,c_out] (flat).  Dense layers are k = 1 on [n,1,1,c].
+    n_store_ld: (n_store, ld_out) override for narrow outputs (D's logit)."""
+    cx = ctx()
+    assert x.ld % 32 == 0, "conv input must be channel-padded to 32"
+    c_in, ci_p, co_p = x.c, x.ld, pad32(c_out)
+    t = k * k
+    needs_w = cx.trains() and kernel_grad is not None
+    needs_x = cx.tape is not None and x.requires_grad
+    scale = None
+    if wn is not None:
+        scale = cx.scratch('wns', c_out)
+        _call('tg_wn_scale_f32', _p(kernel), _p(wn[0]), t * c_in, c_out, _p(scale), cx.stream)
+    w_oti = cx.scratch('woti', co_p * t * ci_p)
+    w_hwio = cx.scratch('whwio', t * ci_p * co_p) if needs_x else None
+    _call('tg_filter_prep_f32', _p(kernel), _p(scale), t, c_in, c_out, ci_p, co_p, _p(w_hwio), _p(w_oti), t * ci_p, ci_p, cx.stream)
+    if n_store_ld is None:
+        n_store, ld_out = c_out, co_p
+    else:
+        n_store, ld_out = n_store_ld
+    fused_act = act if mobn is None else None
+    d = geom.conv_fwd(x.n, x.h, x.w, ci_p, co_p, k, stride, padding, ld_out=ld_out, n_store=n_store, act=fused_act, alpha=alpha)
+    y = cx.new_act(x.n, d.h_out, d.w_out, c_out, ld_out, requires_grad=needs_w or needs_x)
+    _call('tg_igemm_f32', d, x.ptr, _p(w_oti), (_p(bias) if mobn is None else None), y.ptr, cx.stream)
+    seg_rows = _segs(y, segments)
+    if mobn is not None:
+        b, b_grad, pop = mobn
+        sums = None
+        if train:
+            sums, _ = colstats(0, y.t, y.ld, None, 0, y.rows, c_out, seg_rows)
+        shift = cx.scratch('shift', len(seg_rows) * c_out)
+        _call('tg_mobn_finalize_f32', _p(sums), seg_array(seg_rows), len(seg_rows), y.rows, c_out, _p(b), _p(pop), 0.9,
+              1 if train else 0, _p(shift), cx.stream)
+        _call('tg_seg_scale_shift_act_f32', y.ptr, y.ld, y.ptr, y.ld, y.rows, c_out, c_out, seg_array(seg_rows), len(seg_rows),
+              None, _p(shift), ACT[act], alpha, cx.stream)
+
+    if not (needs_w or needs_x):
+        return y
+
+    def bwd():
+        gy = y.grad
+        assert gy is not None, "conv2d backward: no gradient reached the output"
+        if mobn is None and act is None and gy.ld == co_p:
+            dpre = gy.t                                   # the loss head already wrote a padded dlogits
+            if needs_w and bias_grad is not None:
+                colstats(0, dpre, co_p, None, 0, y.rows, c_out, [y.rows], s1=bias_grad)
+        else:
+            dpre = cx.scratch('dpre', y.rows * co_p)
+        if mobn is None and dpre is gy.t:
+            pass
+        elif mobn is not None:
+            sums, _ = colstats(2, gy.t, gy.ld, y.t, y.ld, y.rows, c_out, seg_rows, act, alpha)
+            sh = cx.scratch('bshift', len(seg_rows) * c_out)
+            db = mobn[1] if needs_w else cx.scratch('db', c_out)
+            _call('tg_mobn_bwd_finalize_f32', _p(sums), seg_array(seg_rows), len(seg_rows), y.rows, c_out, _p(sh), _p(db), cx.stream)
+            _call('tg_seg_actgrad_shift_f32', gy.ptr, gy.ld, y.ptr, y.ld, _p(dpre), co_p, y.rows, c_out, seg_array(seg_rows),
+                  len(seg_rows), _p(sh), ACT[act], alpha, cx.stream)
+        else:
+            _call('tg_actgrad_f32', gy.ptr, gy.ld, y.ptr if act else None, y.ld, None, 0, 1.0, _p(dpre), co_p, y.rows, c_out,
+                  ACT[act], alpha, cx.stream)
+            if needs_w and bias_grad is not None:
+                colstats(0, dpre, co_p, None, 0, y.rows, c_out, [y.rows], s1=bias_grad)
+        if needs_w:
+            dw_desc = geom.conv_wgrad(x.n, x.h, x.w, ci_p, co_p, k, stride, padding)
+            if wn is None:
+                filter_grad(dw_desc, x.t, dpre, t, c_in, c_out, kernel_grad)
+            else:
+                dw = cx.scratch('dw', t * c_in * c_out)
+                filter_grad(dw_desc, x.t, dpre, t, c_in, c_out, dw)
+                coef = cx.scratch('coef', 2 * c_out)
+                _call('tg_wn_bwd_f32', _p(dw), _p(kernel), _p(wn[0]), t * c_in, c_out, _p(kernel_grad), _p(wn[1]), _p(coef), cx.stream)
+        if needs_x:
+            gx = cx.grad_of(x)
+            for dd in geom.conv_dgrad(x.n, x.h, x.w, ci_p, co_p, k, stride, padding, ld_out=gx.ld, n_store=ci_p):
+                _call('tg_igemm_f32', dd, _p(dpre), _p(w_hwio), None, gx.ptr, cx.stream)
+
+    cx.record(bwd)
+    return y
+
+
+def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None, narrow_out=False):
+    """tf.layers.conv2d_transpose 5x5 s2 'same' + bias + act (Model/modle_base.py:246-259);
+    kernel [5,5,c_out,c_in].  narrow_out: store only the logical channels (generator output)."""
+    cx = ctx()
+    assert x.ld % 32 == 0
+    c_in, ci_p, co_p = x.c, x.ld, pad32(c_out)
+    needs_w = cx.trains() and kernel_grad is not None
+    needs_x = cx.tape is not None and x.requires_grad
+    w_pad = cx.scratch('wpad', 25 * co_p * ci_p)
+    w_tr = cx.scratch('wtr', 25 * ci_p * co_p) if needs_x else None
+    _call('tg_filter_prep_f32', _p(kernel), None, 25, c_out, c_in, co_p, ci_p, _p(w_pad), _p(w_tr), co_p, ci_p * co_p, cx.stream)
+    ld_out = c_out if narrow_out else co_p
+    y = cx.new_act(x.n, 2 * x.h, 2 * x.w, c_out, ld_out, requires_grad=needs_w or needs_x)
+    for d in geom.deconv_fwd(x.n, x.h, x.w, ci_p, co_p, ld_out=ld_out, n_store=c_out, act=act):
+        _call('tg_igemm_f32', d, x.ptr, _p(w_pad), _p(bias), y.ptr, cx.stream)
+    if not (needs_w or needs_x):
+        return y
+
+    def bwd():
+        gy = y.grad
+        assert gy is not None
+        dpre = cx.scratch('dpre', y.rows * co_p)
+        _call('tg_actgrad_f32', gy.ptr, gy.ld, y.ptr if act else None, y.ld, None, 0, 1.0, _p(dpre), co_p, y.rows, c_out,
+              ACT[act], 0.2, cx.stream)
+        if needs_w:
+            if bias_grad is not None:
+                colstats(0, dpre, co_p, None, 0, y.rows, c_out, [y.rows], s1=bias_grad)
+            filter_grad(geom.deconv_wgrad(x.n, x.h, x.w, co_p, ci_p), dpre, x.t, 25, c_out, c_in, kernel_grad)
+        if needs_x:
+            gx = cx.grad_of(x)
+            _call('tg_igemm_f32', geom.deconv_dgrad(x.n, x.h, x.w, ci_p, co_p, ld_out=gx.ld, n_store=ci_p), _p(dpre), _p(w_tr), None,
+                  gx.ptr, cx.stream)
+
+    cx.record(bwd)
+    return y
+
+
+# ------------------------------------------------------------------ batch norm (tf.contrib.layers.batch_norm, training mode)
+
+def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_grad=None, relu_input=False):
+    """y = gamma*(x-mu)/sqrt(var+eps)+beta over all rows (Model/modle_base.py:229-237).
+    relu_input: x is the output of a fused ReLU; the backward then also masks by x > 0 and the
+    gradient it produces is wrt the PRE-ReLU value (consumed by the producing conv's backward)."""
+    cx = ctx()
+    c = x.c
+    trains = cx.trains()
+    needs = cx.tape is not None and (x.requires_grad or trains)
+    s1, s2 = colstats(1, x.t, x.ld, None, 0, x.rows, c, [x.rows])
+    scale, shift, mean_inv = cx.scratch('bnsc', c), cx.scratch('bnsh', c), cx.scratch('bnmi', 2 * c)
+    _call('tg_bn_finalize_f32', _p(s1), _p(s2), x.rows, c, _p(gamma), _p(beta), eps, _p(scale), _p(shift), _p(mean_inv), _p(mm), _p(mv),
+          decay, 1 if (x.h * x.w > 1) else 0, cx.stream)
+    y = cx.new_act(x.n, x.h, x.w, c, x.ld, requires_grad=needs)
+    _call('tg_seg_scale_shift_act_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, c, seg_array([x.rows]), 1, _p(scale), _p(shift), 0, 0.0,
+          cx.stream)
+    if not needs:
+        return y
+
+    def bwd():
+        gy = y.grad
+        assert gy is not None
+        sdy, sdyx = colstats(3, gy.t, gy.ld, x.t, x.ld, x.rows, c, [x.rows])
+        abc = cx.scratch('abc', 3 * c)
+        dg = gamma_grad if (trains and gamma_grad is not None) else cx.scratch('dgm', c)
+        db = beta_grad if (trains and beta_grad is not None) else cx.scratch('dbt', c)
+        _call('tg_bn_bwd_finalize_f32', _p(sdy), _p(sdyx), x.rows, c, _p(gamma), _p(mean_inv), _p(abc), _p(dg), _p(db), cx.stream)
+        gx = cx.grad_of(x)
+        _call('tg_bn_bwd_apply_f32', gy.ptr, gy.ld, x.ptr, x.ld, gx.ptr, gx.ld, x.rows, c, _p(abc), 1 if relu_input else 0, cx.stream)
+
+    cx.record(bwd)
+    return y
+
+
+# ------------------------------------------------------------------ pointwise / pooling / concat
+
+def scale_mask(x, mask_t, mscale):
+    """y = x*mask*mscale (inverted dropout, Model/modle_base.py:190-191)."""
+    cx = ctx()
+    y = cx.new_act(x.n, x.h, x.w, x.c, x.ld, requires_grad=x.requires_grad)
+    _call('tg_actgrad_f32', x.ptr, x.ld, None, 0, _p(mask_t), x.c, mscale, y.ptr, y.ld, x.rows, x.c, 0, 0.0, cx.stream)
+    if cx.tape is not None and x.requires_grad:
+        def bwd():
+            gx = cx.grad_of(x)
+            _call('tg_actgrad_f32', y.grad.ptr, y.grad.ld, None, 0, _p(mask_t), x.c, mscale, gx.ptr, gx.ld, x.rows, x.c, 0, 0.0, cx.stream)
+        cx.record(bwd)
+    return y
+
+
+def cond_concat(x, y_onehot_t, ncls):
+    """concat([x, y*ones], 3), output channel-padded to 32 (Model/modle_base.py:239-244)."""
+    cx = ctx()
+    ld = pad32(x.c + ncls)
+    out = cx.new_act(x.n, x.h, x.w, x.c + ncls, ld, requires_grad=x.requires_grad)
+    _call('tg_cond_concat_f32', x.ptr, x.ld, x.c, None, 0, 1.0, _p(y_onehot_t), ncls, out.ptr, ld, x.n, x.h * x.w, cx.stream)
+    if cx.tape is not None and x.requires_grad:
+        def bwd():   # gradient of the first x.c channels; the label channels are constants
+            gx = cx.grad_of(x)
+            _call('tg_actgrad_f32', out.grad.ptr, out.grad.ld, None, 0, None, 0, 1.0, gx.ptr, gx.ld, x.rows, x.c, 0, 0.0, cx.stream)
+        cx.record(bwd)
+    return out
+
+
+def pad_add(x, add_t, ld_out):
+    """x + noise, channel-padded (classifier input; no gradient is ever needed upstream)."""
+    cx = ctx()
+    out = cx.new_act(x.n, x.h, x.w, x.c, ld_out)
+    _call('tg_pad_add_f32', x.ptr, x.ld, x.c, _p(add_t), x.c, out.ptr, ld_out, x.rows, cx.stream)
+    return out
+
+
+def maxpool2_dropout(y, mask_t, mscale):
+    """tf.nn.max_pool 2x2 + tf.layers.dropout (Model/Good_GAN_cifar10.py:123-124)."""
+    cx = ctx()
+    out = cx.new_act(y.n, y.h // 2, y.w // 2, y.c, y.ld, requires_grad=y.requires_grad)
+    _call('tg_maxpool2_fwd_f32', y.ptr, y.ld, out.ptr, out.ld, _p(mask_t), y.c, mscale, y.n, y.h, y.w, y.c, cx.stream)
+    if cx.tape is not None and y.requires_grad:
+        def bwd():
+            gy = cx.grad_of(y)
+            _call('tg_maxpool2_bwd_f32', out.grad.ptr, out.grad.ld, _p(mask_t), y.c, mscale, y.ptr, y.ld, gy.ptr, gy.ld, y.n, y.h, y.w,
+                  y.c, cx.stream)
+        cx.record(bwd)
+    return out
+
+
+def global_maxpool(x):
+    cx = ctx()
+    out = cx.new_act(x.n, 1, 1, x.c, pad32(x.c), requires_grad=x.requires_grad)
+    _call('tg_gmaxpool_fwd_f32', x.ptr, x.ld, out.ptr, out.ld, x.n, x.h * x.w, x.c, cx.stream)
+    if cx.tape is not None and x.requires_grad:
+        def bwd():
+            gx = cx.grad_of(x)
+            _call('tg_gmaxpool_bwd_f32', out.grad.ptr, out.grad.ld, x.ptr, x.ld, gx.ptr, gx.ld, x.n, x.h * x.w, x.c, cx.stream)
+        cx.record(bwd)
+    return out
+
+
+def global_avgpool_concat(x, y_onehot_t, ncls):
+    """average_pooling2d over the whole map + squeeze + concat([h, y], 1) (Good_GAN_cifar10.py:94-96)."""
+    cx = ctx()
+    out = cx.new_act(x.n, 1, 1, x.c + ncls, pad32(x.c + ncls), requires_grad=x.requires_grad)
+    _call('tg_gavgpool_concat_f32', x.ptr, x.ld, x.c, _p(y_onehot_t), ncls, out.ptr, out.ld, x.n, x.h * x.w, cx.stream)
+    if cx.tape is not None and x.requires_grad:
+        def bwd():
+            gx = cx.grad_of(x)
+            _call('tg_gavgpool_bwd_f32', out.grad.ptr, out.grad.ld, x.ptr, x.ld, gx.ptr, gx.ld, x.n, x.h * x.w, x.c, 0, 0.0, cx.stream)
+        cx.record(bwd)
+    return out
+
+
+def argmax_onehot(logits, k):
+    cx = ctx()
+    out = cx.scratch('oh', logits.n * k)
+    _call('tg_argmax_onehot_f32', logits.ptr, logits.ld, logits.n, k, _p(out), cx.stream)
+    return out
+
+
+def copy_rows(dst_t, dst_off, src_t, numel):
+    """contiguous device copy (batch concatenation along N)."""
+    cx = ctx()
+    _call('tg_copy2d_f32', C.c_void_p(src_t.data_ptr()), numel, C.c_void_p(dst_t.data_ptr() + 4 * dst_off), numel, 1, numel, cx.stream)
+
+
+def reshape(x, n, h, w, c):
+    """view change of a dense (ld == c) buffer, e.g. [N,8192] -> [N,4,4,512]; gradients share storage."""
+    cx = ctx()
+    assert x.ld == x.c and n * h * w * c == x.rows * x.c
+    y = Act(x.t, n, h, w, c, c, x.requires_grad)
+    if cx.tape is not None and x.requires_grad:
+        def bwd():
+            g = y.grad
+            x.grad = Act(g.t, x.n, x.h, x.w, x.c, x.c)
+        cx.record(bwd)
+    return y

@@ -1,0 +1,333 @@
+"""Eager execution context under the reference's op surface.
+
+TensorFlow graph-mode concepts have no equivalent here: instead of placeholders,
+variable scopes and a Session there is ONE `Context` holding
+  * the persistent device workspace (every activation / gradient buffer is allocated once, keyed by
+    the call-site sequence of a phase, so that a captured hipGraph can replay the step),
+  * the flat per-network parameter / gradient / Adam-slot buffers (`ParamStore`),
+  * the backward tape of the phase being executed (explicit closures; no autograd engine),
+  * the RNG provider (Philox kernels, or tensors injected by the parity tests).
+torch is used only as the device-buffer substrate (allocation, H2D copies, streams).
+"""
+import contextlib
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib
+
+
+def pad32(c):
+    return (c + 31) // 32 * 32
+
+
+class Act(object):
+    """Handle of an NHWC activation buffer: logical shape [n,h,w,c], channel stride ld >= c
+    (channels c..ld are zero when the buffer feeds an MFMA kernel)."""
+    __slots__ = ('t', 'n', 'h', 'w', 'c', 'ld', 'grad', 'requires_grad')
+
+    def __init__(self, t, n, h, w, c, ld, requires_grad=False):
+        self.t, self.n, self.h, self.w, self.c, self.ld = t, n, h, w, c, ld
+        self.grad = None
+        self.requires_grad = requires_grad
+
+    @property
+    def rows(self):
+        return self.n * self.h * self.w
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.t.data_ptr())
+
+    def numpy(self):
+        """logical [n,h,w,c] (or [n,c] when h=w=1) host copy — tests / evaluation only."""
+        a = self.t.detach().cpu().numpy().reshape(self.n, self.h, self.w, self.ld)[..., :self.c]
+        return a.reshape(self.n, self.c) if self.h == 1 and self.w == 1 else a
+
+    def view_rows(self, r0, r1):
+        """sub-batch [r0:r1) of images sharing the same storage."""
+        per = self.h * self.w * self.ld
+        return Act(self.t[r0 * per:r1 * per], r1 - r0, self.h, self.w, self.c, self.ld, self.requires_grad)
+
+
+class ParamStore(object):
+    """One network's variables in flat fp32 device buffers: `p` (trainable values), `g` (gradients),
+    `m`, `v` (Adam slots), `s` (non-trainable state: pop_mean, BN moving statistics).  Offsets are
+    32-float aligned; the padding stays zero (zero gradient => Adam leaves it at zero)."""
+
+    def __init__(self, name, specs, device):
+        self.name = name
+        self.specs = list(specs)                      # (name, shape, trainable)
+        self.index = {}
+        off_p = off_s = 0
+        for nm, shape, trainable in self.specs:
+            n = int(np.prod(shape))
+            if trainable:
+                self.index[nm] = ('p', off_p, n, tuple(shape))
+                off_p += pad32(n)
+            else:
+                self.index[nm] = ('s', off_s, n, tuple(shape))
+                off_s += pad32(n)
+        self.n_p, self.n_s = off_p, max(off_s, 32)
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=device)
+        self.p, self.g, self.m, self.v, self.s = z(self.n_p), z(self.n_p), z(self.n_p), z(self.n_p), z(self.n_s)
+        self.step = torch.zeros(1, dtype=torch.int32, device=device)
+        self.ema = None
+
+    def names(self, trainable=None):
+        return [nm for nm, _, tr in self.specs if trainable is None or tr == trainable]
+
+    def _slice(self, buf, nm):
+        kind, off, n, shape = self.index[nm]
+        return buf[off:off + n]
+
+    def value(self, nm):
+        kind = self.index[nm][0]
+        return self._slice(self.p if kind == 'p' else self.s, nm)
+
+    def grad(self, nm):
+        assert self.index[nm][0] == 'p', nm
+        return self._slice(self.g, nm)
+
+    def shape(self, nm):
+        return self.index[nm][3]
+
+    def set(self, nm, array):
+        v = self.value(nm)
+        a = np.ascontiguousarray(array, np.float32).reshape(-1)
+        assert a.size == v.numel(), (nm, a.size, v.numel())
+        v.copy_(torch.from_numpy(a))
+
+    def get(self, nm, which='value'):
+        t = {'value': self.value, 'grad': self.grad}.get(which)
+        if t is None:
+            t = lambda n: self._slice(getattr(self, which), n)
+        return t(nm).detach().cpu().numpy().reshape(self.shape(nm))
+
+    def load_dict(self, d):
+        for nm in self.names():
+            if nm in d:
+                self.set(nm, d[nm])
+
+    def to_dict(self, which='value'):
+        return {nm: self.get(nm, which) for nm in self.names(None if which == 'value' else True)}
+
+    def enable_ema(self):
+        self.ema = self.p.clone()
+
+
+class InjectedRNG(object):
+    """Parity-test RNG: every draw is looked up in a dict of host arrays keyed '<rng_scope>/<name>'."""
+
+    def __init__(self, arrays, device):
+        self.arrays, self.device, self.cache = arrays, device, {}
+
+    def _get(self, ctx, name, n):
+        key = ctx.rng_scope + '/' + name
+        if key not in self.cache:
+            a = np.ascontiguousarray(self.arrays[key], np.float32).reshape(-1)
+            assert a.size == n, (key, a.size, n)
+            self.cache[key] = torch.from_numpy(a).to(self.device)
+        return self.cache[key]
+
+    def keep_mask(self, ctx, name, n, keep):
+        return self._get(ctx, name, n)
+
+    def normal(self, ctx, name, n, std):
+        return self._get(ctx, name, n)       # injected noise is already scaled by std
+
+    def advance(self, ctx):
+        pass
+
+
+class PhiloxRNG(object):
+    """Production RNG: tg_rng_* kernels; (seed, step) in device memory so hipGraph replays draw fresh numbers."""
+
+    def __init__(self, seed, device):
+        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        self.stream_ids = {}
+
+    def _sid(self, ctx, name):
+        key = ctx.rng_scope + '/' + name
+        if key not in self.stream_ids:
+            self.stream_ids[key] = len(self.stream_ids) + 1
+        return self.stream_ids[key]
+
+    def keep_mask(self, ctx, name, n, keep):
+        out = ctx.ws('rng:' + ctx.rng_scope + '/' + name, n)
+        lib.call('tg_rng_keep_mask_f32', lib.ptr(out), n, keep, lib.ptr(self.state), self._sid(ctx, name), ctx.stream)
+        return out
+
+    def normal(self, ctx, name, n, std):
+        out = ctx.ws('rng:' + ctx.rng_scope + '/' + name, n)
+        lib.call('tg_rng_normal_f32', lib.ptr(out), n, std, lib.ptr(self.state), self._sid(ctx, name), ctx.stream)
+        return out
+
+    def uniform(self, ctx, name, n, lo, hi, out=None):
+        out = ctx.ws('rng:' + ctx.rng_scope + '/' + name, n) if out is None else out
+        lib.call('tg_rng_uniform_f32', lib.ptr(out), n, lo, hi, lib.ptr(self.state), self._sid(ctx, name), ctx.stream)
+        return out
+
+    def onehot(self, ctx, name, rows, k, out=None):
+        out = ctx.ws('rng:' + ctx.rng_scope + '/' + name, rows * k) if out is None else out
+        lib.call('tg_rng_onehot_f32', lib.ptr(out), rows, k, lib.ptr(self.state), self._sid(ctx, name), ctx.stream)
+        return out
+
+    def advance(self, ctx):
+        lib.call('tg_rng_advance', lib.ptr(self.state), ctx.stream)
+
+
+class Context(object):
+    def __init__(self, device='cuda:0', seed=0):
+        lib.load()                                   # fails loudly when the HIP extension is missing
+        if not torch.cuda.is_available():
+            raise lib.TgError("no MI355X visible: the Triple-GAN step has no CPU fallback")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        # a dedicated non-default stream: hipStream capture is illegal on the legacy null stream
+        self.torch_stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.set_stream(self.torch_stream)
+        self.buffers = {}
+        self.stores = {}
+        self.tape = None
+        self.phase = 'init'
+        self.counter = 0
+        self.scopes = []
+        self.rng_scope = ''
+        self.rng_counters = {}
+        self.rng = PhiloxRNG(seed, self.device)
+        self.train_nets = set()
+        self._stream = None
+
+    # ---- streams ---------------------------------------------------------------------------------
+    @property
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- workspace -------------------------------------------------------------------------------
+    def ws(self, key, numel, zero=False):
+        t = self.buffers.get(key)
+        if t is None or t.numel() < numel:
+            t = torch.zeros(int(numel), dtype=torch.float32, device=self.device)
+            self.buffers[key] = t
+        elif zero:
+            lib.call('tg_fill_f32', lib.ptr(t), 0.0, int(numel), self.stream)
+        return t[:numel]
+
+    def new_act(self, n, h, w, c, ld=None, requires_grad=False, tag='a'):
+        ld = c if ld is None else ld
+        self.counter += 1
+        key = '%s/%s%d' % (self.phase, tag, self.counter)
+        return Act(self.ws(key, n * h * w * ld), n, h, w, c, ld, requires_grad)
+
+    def scratch(self, tag, numel):
+        self.counter += 1
+        return self.ws('%s/%s%d' % (self.phase, tag, self.counter), numel)
+
+    def grad_of(self, a):
+        """gradient buffer of an activation (same layout), allocated on first use per call site."""
+        if a.grad is None:
+            self.counter += 1
+            a.grad = Act(self.ws('%s/g%d' % (self.phase, self.counter), a.rows * a.ld), a.n, a.h, a.w, a.c, a.ld)
+        return a.grad
+
+    def from_numpy(self, x, ld=None, key=None):
+        """host array [n,h,w,c] or [n,c] -> device Act (tests, data feeding)."""
+        x = np.asarray(x, np.float32)
+        if x.ndim == 2:
+            x = x.reshape(x.shape[0], 1, 1, x.shape[1])
+        n, h, w, c = x.shape
+        ld = c if ld is None else ld
+        if ld != c:
+            xp = np.zeros((n, h, w, ld), np.float32)
+            xp[..., :c] = x
+            x = xp
+        if key is None:
+            t = torch.from_numpy(np.ascontiguousarray(x)).to(self.device).reshape(-1)
+        else:
+            t = self.ws(key, x.size)
+            t.copy_(torch.from_numpy(np.ascontiguousarray(x).reshape(-1)))
+        return Act(t, n, h, w, c, ld)
+
+    # ---- phases / scopes -------------------------------------------------------------------------
+    @contextlib.contextmanager
+    def phase_scope(self, name, train_nets=(), record=True):
+        """one solver run (sess.run of Training/Train_goodGAN.py:266-276): fresh call-site counter and tape."""
+        prev = (self.phase, self.counter, self.tape, self.train_nets)
+        self.phase, self.counter = name, 0
+        self.tape = [] if record else None
+        self.train_nets = set(train_nets)
+        try:
+            yield self
+        finally:
+            self.phase, self.counter, self.tape, self.train_nets = prev
+
+    @contextlib.contextmanager
+    def variable_scope(self, name):
+        self.scopes.append(name)
+        try:
+            yield
+        finally:
+            self.scopes.pop()
+
+    @contextlib.contextmanager
+    def rng_scoped(self, name):
+        prev, self.rng_scope = (self.rng_scope, self.rng_counters), name
+        self.rng_counters = {}
+        try:
+            yield
+        finally:
+            self.rng_scope, self.rng_counters = prev
+
+    def next_rng_name(self, kind):
+        """'drop0', 'drop1', ... in call order inside the current rng scope (one network application batch)."""
+        i = self.rng_counters.get(kind, 0)
+        self.rng_counters[kind] = i + 1
+        return '%s%d' % (kind, i)
+
+    def scope_name(self, leaf=''):
+        return '/'.join(self.scopes + ([leaf] if leaf else []))
+
+    def store_of(self, full_name):
+        return self.stores[full_name.split('/')[0]]
+
+    def var(self, leaf):
+        """device tensor of variable '<scope>/<leaf>' (tf.get_variable with reuse=True)."""
+        full = self.scope_name(leaf)
+        return self.store_of(full).value(full)
+
+    def var_grad(self, leaf):
+        full = self.scope_name(leaf)
+        return self.store_of(full).grad(full)
+
+    def trains(self, leaf=''):
+        return self.tape is not None and self.scope_name(leaf).split('/')[0] in self.train_nets
+
+    def record(self, fn):
+        if self.tape is not None:
+            self.tape.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+
+_CTX = None
+
+
+def set_context(ctx):
+    global _CTX
+    _CTX = ctx
+    return ctx
+
+
+def ctx():
+    if _CTX is None:
+        raise lib.TgError("no tg Context: create tg.runtime.Context() first (needs an MI355X)")
+    return _CTX
+
+
+def seg_array(segs):
+    return (C.c_int32 * len(segs))(*segs)

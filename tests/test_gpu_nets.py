@@ -1,0 +1,131 @@
+"""GPU parity of the three CIFAR-10 networks (forward + backward through the C ABI) against the oracle,
+with identical parameters and injected randomness.  fp32 tolerance: 2e-4 of the tensor's max magnitude for
+activations, 2e-3 for parameter gradients (long fp32 reductions in a different order)."""
+import numpy as np
+import pytest
+
+from oracle import nets_cifar10 as N
+from oracle import step_cifar10 as S
+from oracle import tf_ops as T
+import gpu_common as G
+
+pytestmark = pytest.mark.gpu
+ACT_TOL, GRAD_TOL = 2e-4, 2e-3
+
+
+def scrambled_params(seed):
+    P = S.init_params(seed)
+    rng = np.random.default_rng(seed + 100)
+    for k in P:
+        if k.endswith(('/g', 'gamma')):
+            P[k] = (1 + 0.3 * rng.standard_normal(P[k].shape)).astype(np.float32)
+        elif k.endswith(('/b', 'bias', 'beta')):
+            P[k] = (0.1 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    return P
+
+
+@pytest.fixture(scope="module")
+def trainer():
+    P = scrambled_params(0)
+    tr = G.fresh_trainer(G.make_config(dict(B_G=6, L_C=3, U_C=2, L_D=2, U_D=4)), P)
+    return tr, P
+
+
+def test_classifier_fwd_bwd_two_segments(trainer):
+    from tg.runtime import Act, InjectedRNG
+    tr, P = trainer
+    cx, m = tr.cx, tr.model
+    sizes = dict(S.SIZES, L_C=3, U_C=2)
+    rnd = S.synth_rnd(1, sizes)
+    r1, r2 = rnd['C']['C_real'], rnd['C']['C_unl']
+    b = S.synth_batch(2, sizes)
+    x1, x2 = b['x_l_c'], b['x_u_c']
+    P0 = {k: v.copy() for k, v in P.items()}
+    pops = {}
+    l1, f1, c1 = N.classifier_fwd(P0, x1, True, r1, pops)
+    l2, f2, c2 = N.classifier_fwd(P0, x2, True, r2, pops)
+    rng = np.random.default_rng(3)
+    dl = rng.standard_normal((5, 10)).astype(np.float32)
+    g1 = N.classifier_bwd(P0, c1, dl[:3], r1)
+    g2 = N.classifier_bwd(P0, c2, dl[3:], r2)
+
+    cx.rng = InjectedRNG({'T/C/' + k: v for k, v in G.cat_rnd(r1, r2).items()}, cx.device)
+    with cx.phase_scope('T', train_nets=('classifier',)):
+        xa = cx.from_numpy(np.concatenate([x1, x2]))
+        with cx.rng_scoped('T/C'):
+            logits, feat = m.classifier(xa, True, segments=[3, 2])
+        logits.grad = cx.from_numpy(dl, ld=32)
+        cx.backward()
+    assert G.rel_err(logits.numpy(), np.concatenate([l1, l2])) < ACT_TOL
+    assert G.rel_err(feat.numpy(), np.concatenate([f1, f2])) < ACT_TOL
+    st = cx.stores['classifier']
+    for k in g1:
+        assert G.rel_err(st.get(k, 'grad'), g1[k] + g2[k]) < GRAD_TOL, k
+    for p, v in pops.items():   # sequential pop_mean updates in call-site order
+        assert G.rel_err(st.get(p + 'meanOnlyBatchNormalization/pop_mean'), v) < ACT_TOL, p
+    # evaluation mode uses the accumulated pop_mean, keeps the noise, drops the dropout
+    for p, v in pops.items():
+        P0[p + 'meanOnlyBatchNormalization/pop_mean'] = v
+    le, _, _ = N.classifier_fwd(P0, x1, False, r1)
+    cx.rng = InjectedRNG({'E/C/noise': r1['noise']}, cx.device)
+    with cx.phase_scope('E', record=False):
+        with cx.rng_scoped('E/C'):
+            logits_e, _ = m.classifier(cx.from_numpy(x1), False)
+    assert G.rel_err(logits_e.numpy(), le) < ACT_TOL
+
+
+def test_generator_fwd_bwd(trainer):
+    tr, P = trainer
+    cx, m = tr.cx, tr.model
+    b = S.synth_batch(4, dict(S.SIZES, B_G=6))
+    out, c = N.generator_fwd(P, b['z_g'], b['y_g'])
+    do = np.random.default_rng(5).standard_normal(out.shape).astype(np.float32)
+    gref = N.generator_bwd(P, c, do)
+    with cx.phase_scope('T2', train_nets=('good_generator',)):
+        o = m.good_generator(cx.from_numpy(b['z_g']), cx.from_numpy(b['y_g']))
+        o.grad = cx.from_numpy(do)
+        cx.backward()
+    assert G.rel_err(o.numpy(), out) < ACT_TOL
+    st = cx.stores['good_generator']
+    for k in gref:
+        assert G.rel_err(st.get(k, 'grad'), gref[k]) < GRAD_TOL, k
+    # sampler == generator graph with reuse (BN in training mode)
+    with cx.phase_scope('T2s', record=False):
+        s = m.good_sampler(cx.from_numpy(b['z_g']), cx.from_numpy(b['y_g']))
+    assert G.rel_err(s.numpy(), out) < ACT_TOL
+
+
+def test_discriminator_fwd_bwd_weights_and_input(trainer):
+    from tg.runtime import InjectedRNG
+    tr, P = trainer
+    cx, m = tr.cx, tr.model
+    n = 5
+    rnd = S.synth_rnd(7, dict(S.SIZES, B_G=n))['G']['D_fake']
+    y = np.eye(10, dtype=np.float32)[np.random.default_rng(8).integers(0, 10, n)]
+    img = np.tanh(np.random.default_rng(9).standard_normal((n, 32, 32, 3))).astype(np.float32)
+    logits, c = N.discriminator_fwd(P, img, y, rnd)
+    dl = np.random.default_rng(10).standard_normal(logits.shape).astype(np.float32)
+    gref, dimg = N.discriminator_bwd(P, c, dl, rnd, True, True)
+    cx.rng = InjectedRNG({'T3/D/' + k: v for k, v in rnd.items()}, cx.device)
+    with cx.phase_scope('T3', train_nets=('discriminator',)):
+        ia = cx.from_numpy(img)
+        ia.requires_grad = True
+        with cx.rng_scoped('T3/D'):
+            _, lg = m.discriminator(ia, cx.from_numpy(y))
+        lg.grad = cx.from_numpy(dl, ld=32)
+        cx.backward()
+    assert G.rel_err(lg.numpy(), logits) < ACT_TOL
+    st = cx.stores['discriminator']
+    for k in gref:
+        assert G.rel_err(st.get(k, 'grad'), gref[k]) < GRAD_TOL, k
+    assert G.rel_err(ia.grad.numpy(), dimg) < GRAD_TOL
+
+
+def test_zca_matches_oracle(trainer):
+    tr, _ = trainer
+    cx, m = tr.cx, tr.model
+    x = S.synth_batch(11, dict(S.SIZES, L_C=7))['x_l_c']
+    mean, mat = G.zca()
+    with cx.phase_scope('T4', record=False):
+        out = m.zca().apply(cx.from_numpy(x))
+    assert G.rel_err(out.numpy(), N.zca_apply(x, mean, mat)) < ACT_TOL
