@@ -116,7 +116,8 @@ int tg_wn_bwd_f32(const float* dw, const float* v, const float* g, int rows, int
  * discriminator application batched into the launch); seg_rows is a HOST array of nseg row counts. */
 int64_t tg_colstats_workspace_floats(int rows, int nseg, int c);
 /* Per-(segment, channel) sums, deterministic two-stage reduction.  mode 0: s1 = sum a; 1: s1 = sum a, s2 = sum a^2;
- * 2: s1 = sum a*act'(b) (b = activation output); 3: s1 = sum a, s2 = sum a*b.  s1/s2: [nseg][c].
+ * 2: s1 = sum a*act'(b) (b = activation output); 3: s1 = sum a, s2 = sum a*b; 4: s1 = sum (a - b[c]*alpha)^2 with b the
+ * [c] sums of a mode-0 pass and alpha = 1/rows (centred second moment, one segment).  s1/s2: [nseg][c].
  * tf.nn.moments of mean_only_batch_norm_impl (Model/nn.py:171-175), tf.contrib.layers.batch_norm
  * (Model/modle_base.py:229-237), bias-gradient reductions. */
 int tg_colstats_f32(int mode, const float* a, int ld_a, const float* b, int ld_b, int rows, int c, const int32_t* seg_rows, int nseg, int act,
@@ -133,7 +134,8 @@ int tg_mobn_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, i
                          int train, float* shift, void* stream);
 /* shift[s][k] = -sums[s][k]/rows_s; db[k] = sum_s sums[s][k]. */
 int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, int rows, int c, float* shift, float* db, void* stream);
-/* batch norm (training mode, biased variance): scale = gamma*inv, shift = beta - mean*scale, mean_inv = [mean | inv];
+/* batch norm (training mode, biased variance) from s1 = sum x and s2 = sum (x-mean)^2 (modes 0 and 4 above):
+ * scale = gamma*inv, shift = beta - mean*scale, mean_inv = [mean | inv];
  * moving statistics updated in place when non-NULL (bessel = use the unbiased variance, the fused 4-D kernel). */
 int tg_bn_finalize_f32(const float* s1, const float* s2, int rows, int c, const float* gamma, const float* beta, float eps, float* scale,
                        float* shift, float* mean_inv, float* moving_mean, float* moving_var, float decay, int bessel, void* stream);

@@ -33,6 +33,7 @@ def new_state(P):
 def _adam(st, net, grads, lr, beta1):
     st['t'][net] += 1
     t = st['t'][net]
+    st.setdefault('last_grads', {})[net] = grads          # kept for the parity tests (pre-Adam comparison)
     for k, g in grads.items():
         st['P'][k], st['m'][k], st['v'][k] = T.adam_update(
             st['P'][k], g.astype(st['P'][k].dtype), st['m'][k], st['v'][k], t, lr, beta1)

@@ -422,12 +422,14 @@ def pull_away_unmasked(f):
 # --------------------------------------------------------------------------
 
 def adam_update(p, g, m, v, t, lr, beta1, beta2=0.999, eps=1e-8):
-    """TF form: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps). t counts from 1."""
+    """tf.train.AdamOptimizer as its ApplyAdam functor computes it, in the variable's dtype [UNVERIFIED-TF]:
+    alpha = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); p -= m*alpha/(sqrt(v)+eps).
+    t counts from 1.  (1-b) is formed in the variable's precision, as T(1)-beta does.)"""
     f = p.dtype.type
-    lr_t = f(lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
-    m = f(beta1) * m + f(1 - beta1) * g
-    v = f(beta2) * v + f(1 - beta2) * g * g
-    p = p - lr_t * m / (np.sqrt(v) + f(eps))
+    alpha = f(lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
+    m = m + (g - m) * (f(1) - f(beta1))
+    v = v + (g * g - v) * (f(1) - f(beta2))
+    p = p - m * alpha / (np.sqrt(v) + f(eps))
     return p, m, v
 
 

@@ -24,10 +24,16 @@ __device__ __forceinline__ int seg_of_row(const SegTable& st, int r, int* row_in
   return st.nseg - 1;
 }
 
-// mode: 0 SUM(a) ; 1 SUM(a), SUM(a^2) ; 2 SUM(a*act'(b)) ; 3 SUM(a), SUM(a*b)
+// mode: 0 SUM(a) ; 1 SUM(a), SUM(a^2) ; 2 SUM(a*act'(b)) ; 3 SUM(a), SUM(a*b) ;
+// 4 SUM((a-mu)^2) with mu[c] = b[c]*alpha (b = per-channel sums of a previous mode-0 pass, alpha = 1/rows)
+struct d4 { double x, y, z, w; };
+
+// Partial sums are accumulated in fp64: batch-norm / mean-only-BN backward statistics are sums of mixed-sign terms
+// that cancel to a small remainder, and the bias gradients behind them inherit that remainder coherently over all
+// rows — fp32 accumulation costs ~1e-2 relative error there.  The kernel stays HBM-bound (8 fp64 adds per 16 B).
 template <int MODE>
 __global__ void __launch_bounds__(256) colstats_stage1(const float* __restrict__ a, const float* __restrict__ b, int ld_a, int ld_b,
-                                                        int c4, SegTable st, int act, float alpha, float* __restrict__ part, int c_pad) {
+                                                        int c4, SegTable st, int act, float alpha, double* __restrict__ part, int c_pad) {
   // locate this block's chunk: (segment, row range)
   int ch = blockIdx.y, seg = 0, base = 0;
   for (; seg < st.nseg; ++seg) {
@@ -41,57 +47,65 @@ __global__ void __launch_bounds__(256) colstats_stage1(const float* __restrict__
   const int r1 = min(base + st.rows[seg], r0 + RCH);
   const int cg = blockIdx.x * 32 + (threadIdx.x & 31);   // float4 column group
   const int ry = threadIdx.x >> 5;
-  float4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  d4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
   if (cg < c4) {
+    float4 mu = {0, 0, 0, 0};
+    if (MODE == 4) {
+      mu = *reinterpret_cast<const float4*>(b + cg * 4);
+      mu.x *= alpha; mu.y *= alpha; mu.z *= alpha; mu.w *= alpha;
+    }
     for (int r = r0 + ry; r < r1; r += 8) {
-      float4 va = *reinterpret_cast<const float4*>(a + (int64_t)r * ld_a + cg * 4);
+      const float4 va = *reinterpret_cast<const float4*>(a + (int64_t)r * ld_a + cg * 4);
       if (MODE == 0) {
         s1.x += va.x; s1.y += va.y; s1.z += va.z; s1.w += va.w;
       } else if (MODE == 1) {
         s1.x += va.x; s1.y += va.y; s1.z += va.z; s1.w += va.w;
-        s2.x += va.x * va.x; s2.y += va.y * va.y; s2.z += va.z * va.z; s2.w += va.w * va.w;
+        s2.x += (double)va.x * va.x; s2.y += (double)va.y * va.y; s2.z += (double)va.z * va.z; s2.w += (double)va.w * va.w;
+      } else if (MODE == 4) {
+        const float d0 = va.x - mu.x, d1 = va.y - mu.y, d2 = va.z - mu.z, d3 = va.w - mu.w;
+        s1.x += (double)d0 * d0; s1.y += (double)d1 * d1; s1.z += (double)d2 * d2; s1.w += (double)d3 * d3;
       } else {
-        float4 vb = *reinterpret_cast<const float4*>(b + (int64_t)r * ld_b + cg * 4);
+        const float4 vb = *reinterpret_cast<const float4*>(b + (int64_t)r * ld_b + cg * 4);
         if (MODE == 2) {
           s1.x += va.x * tgd::act_grad(vb.x, act, alpha); s1.y += va.y * tgd::act_grad(vb.y, act, alpha);
           s1.z += va.z * tgd::act_grad(vb.z, act, alpha); s1.w += va.w * tgd::act_grad(vb.w, act, alpha);
         } else {
           s1.x += va.x; s1.y += va.y; s1.z += va.z; s1.w += va.w;
-          s2.x += va.x * vb.x; s2.y += va.y * vb.y; s2.z += va.z * vb.z; s2.w += va.w * vb.w;
+          s2.x += (double)va.x * vb.x; s2.y += (double)va.y * vb.y; s2.z += (double)va.z * vb.z; s2.w += (double)va.w * vb.w;
         }
       }
     }
   }
-  __shared__ float4 red[2][8][32];
+  __shared__ d4 red[2][8][32];
   red[0][ry][threadIdx.x & 31] = s1;
   red[1][ry][threadIdx.x & 31] = s2;
   __syncthreads();
   if (ry == 0 && cg < c4) {
     for (int k = 1; k < 8; ++k) {
-      float4 t1 = red[0][k][threadIdx.x & 31], t2 = red[1][k][threadIdx.x & 31];
+      const d4 t1 = red[0][k][threadIdx.x & 31], t2 = red[1][k][threadIdx.x & 31];
       s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
       s2.x += t2.x; s2.y += t2.y; s2.z += t2.z; s2.w += t2.w;
     }
-    float* o = part + ((int64_t)blockIdx.y * 2) * c_pad + cg * 4;
-    *reinterpret_cast<float4*>(o) = s1;
-    *reinterpret_cast<float4*>(o + c_pad) = s2;
+    double* o = part + ((int64_t)blockIdx.y * 2) * c_pad + cg * 4;
+    o[0] = s1.x; o[1] = s1.y; o[2] = s1.z; o[3] = s1.w;
+    o[c_pad + 0] = s2.x; o[c_pad + 1] = s2.y; o[c_pad + 2] = s2.z; o[c_pad + 3] = s2.w;
   }
 }
 
-__global__ void colstats_stage2(const float* __restrict__ part, SegTable st, int c_pad, int c, float* __restrict__ s1, float* __restrict__ s2) {
+__global__ void colstats_stage2(const double* __restrict__ part, SegTable st, int c_pad, int c, float* __restrict__ s1, float* __restrict__ s2) {
   const int seg = blockIdx.y;
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= c) return;
   int ch0 = 0;
   for (int s = 0; s < seg; ++s) ch0 += (st.rows[s] + RCH - 1) / RCH;
   const int n = (st.rows[seg] + RCH - 1) / RCH;
-  float a1 = 0.f, a2 = 0.f;
+  double a1 = 0., a2 = 0.;
   for (int k = 0; k < n; ++k) {
     a1 += part[((int64_t)(ch0 + k) * 2) * c_pad + col];
     a2 += part[((int64_t)(ch0 + k) * 2 + 1) * c_pad + col];
   }
-  s1[seg * c + col] = a1;
-  if (s2) s2[seg * c + col] = a2;
+  s1[seg * c + col] = (float)a1;
+  if (s2) s2[seg * c + col] = (float)a2;
 }
 
 // y[r][c] = act(x[r][c]*scale[c] + shift[seg(r)][c]) for c < C; zero for C <= c < c_zero_to.
@@ -208,8 +222,7 @@ __global__ void bn_finalize(const float* __restrict__ s1, const float* __restric
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= c) return;
   const float mu = s1[col] / (float)rows;
-  float var = s2[col] / (float)rows - mu * mu;   // biased
-  var = var > 0.f ? var : 0.f;
+  const float var = s2[col] / (float)rows;       // biased; s2 = sum (x-mu)^2 from the second (centred) pass, as tf.nn.moments
   const float inv = 1.f / sqrtf(var + eps);
   const float sc = gamma[col] * inv;
   scale[col] = sc;
@@ -267,7 +280,7 @@ extern "C" {
 int64_t tg_colstats_workspace_floats(int rows, int nseg, int c) {
   // upper bound: every segment adds at most one partial chunk
   int c_pad = (c + 3) / 4 * 4;
-  return (int64_t)((rows + RCH - 1) / RCH + nseg) * 2 * c_pad;
+  return (int64_t)((rows + RCH - 1) / RCH + nseg) * 2 * c_pad * 2;   // fp64 partials
 }
 
 int tg_colstats_f32(int mode, const float* a, int ld_a, const float* b, int ld_b, int rows, int c, const int32_t* seg_rows, int nseg,
@@ -277,21 +290,25 @@ int tg_colstats_f32(int mode, const float* a, int ld_a, const float* b, int ld_b
   if (rc != TG_OK) return rc;
   TG_REQUIRE(a && workspace && s1, "colstats: null buffer");
   TG_REQUIRE(ld_a % 4 == 0 && (b == nullptr || ld_b % 4 == 0), "colstats: ld must be a multiple of 4");
+  TG_REQUIRE(mode != 4 || (nseg == 1 && c % 4 == 0), "colstats: mode 4 needs one segment and c %% 4 == 0");
   TG_REQUIRE((mode == 0 || mode == 1) || b != nullptr, "colstats: mode %d needs operand b", mode);
   const int c4 = (c + 3) / 4, c_pad = c4 * 4;
-  TG_REQUIRE(c_pad <= ld_a && (b == nullptr || c_pad <= ld_b), "colstats: c=%d exceeds ld", c);
+  TG_REQUIRE(c_pad <= ld_a && (b == nullptr || mode == 4 || c_pad <= ld_b), "colstats: c=%d exceeds ld", c);
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_NORM, 0, 4.0 * rows * c * (b ? 2 : 1), s);
   dim3 grid((c4 + 31) / 32, num_chunks(st));
+  TG_REQUIRE((uintptr_t)workspace % 8 == 0, "colstats: workspace must be 8-byte aligned");
+  double* wsd = reinterpret_cast<double*>(workspace);
   switch (mode) {
-    case 0: hipLaunchKernelGGL(colstats_stage1<0>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, workspace, c_pad); break;
-    case 1: hipLaunchKernelGGL(colstats_stage1<1>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, workspace, c_pad); break;
-    case 2: hipLaunchKernelGGL(colstats_stage1<2>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, workspace, c_pad); break;
-    case 3: hipLaunchKernelGGL(colstats_stage1<3>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, workspace, c_pad); break;
+    case 0: hipLaunchKernelGGL(colstats_stage1<0>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, wsd, c_pad); break;
+    case 1: hipLaunchKernelGGL(colstats_stage1<1>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, wsd, c_pad); break;
+    case 2: hipLaunchKernelGGL(colstats_stage1<2>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, wsd, c_pad); break;
+    case 3: hipLaunchKernelGGL(colstats_stage1<3>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, wsd, c_pad); break;
+    case 4: hipLaunchKernelGGL(colstats_stage1<4>, grid, dim3(256), 0, s, a, b, ld_a, ld_b, c4, st, act, alpha, wsd, c_pad); break;
     default: tg::set_error("colstats: bad mode %d", mode); return TG_ERR_INVALID;
   }
   TG_CHECK_LAUNCH("colstats_stage1");
-  hipLaunchKernelGGL(colstats_stage2, dim3((c + 127) / 128, nseg), dim3(128), 0, s, workspace, st, c_pad, c, s1, s2);
+  hipLaunchKernelGGL(colstats_stage2, dim3((c + 127) / 128, nseg), dim3(128), 0, s, wsd, st, c_pad, c, s1, s2);
   TG_CHECK_LAUNCH("colstats_stage2");
   return TG_OK;
 }

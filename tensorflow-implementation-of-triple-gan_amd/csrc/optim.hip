@@ -2,8 +2,8 @@
 // 28 B/param (read p,g,m,v; write p,m,v) — HBM-bound, 16-B lanes, grid-stride.
 // Hyper-parameters that change between iterations (learning rate, step count) live in device memory so that
 // a captured hipGraph replays with fresh values.
-//   tf.train.AdamOptimizer (Training/train_base.py:91-97): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
-//   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m/(sqrt(v)+eps)      [UNVERIFIED-TF]
+//   tf.train.AdamOptimizer (Training/train_base.py:91-97) in its ApplyAdam functor form: alpha = lr*sqrt(1-b2^t)/(1-b1^t);
+//   m += (g-m)(1-b1); v += (g^2-v)(1-b2); p -= m*alpha/(sqrt(v)+eps)              [UNVERIFIED-TF]
 //   tf.train.ExponentialMovingAverage(0.9999).apply (Training/Train_goodGAN.py:101-103): s -= (1-d)(s-p)
 #include "tg_common.h"
 
@@ -25,17 +25,17 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gg = gp[k] * grad_scale;
-      mp[k] = beta1 * mp[k] + omb1 * gg;
-      vp[k] = beta2 * vp[k] + omb2 * gg * gg;
-      pp[k] = pp[k] - lr_t * mp[k] / (sqrtf(vp[k]) + eps);
+      mp[k] = mp[k] + (gg - mp[k]) * omb1;
+      vp[k] = vp[k] + (gg * gg - vp[k]) * omb2;
+      pp[k] = pp[k] - mp[k] * lr_t / (sqrtf(vp[k]) + eps);
     }
     reinterpret_cast<float4*>(p)[i] = pv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
   }
   for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gg = g[i] * grad_scale;
-    const float mm = beta1 * m[i] + omb1 * gg, vv = beta2 * v[i] + omb2 * gg * gg;
+    const float mm = m[i] + (gg - m[i]) * omb1, vv = v[i] + (gg * gg - v[i]) * omb2;
     m[i] = mm; v[i] = vv;
-    p[i] = p[i] - lr_t * mm / (sqrtf(vv) + eps);
+    p[i] = p[i] - mm * lr_t / (sqrtf(vv) + eps);
   }
 }
 

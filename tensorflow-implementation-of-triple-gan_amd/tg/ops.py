@@ -189,7 +189,8 @@ def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_g
     c = x.c
     trains = cx.trains()
     needs = cx.tape is not None and (x.requires_grad or trains)
-    s1, s2 = colstats(1, x.t, x.ld, None, 0, x.rows, c, [x.rows])
+    s1, _ = colstats(0, x.t, x.ld, None, 0, x.rows, c, [x.rows])
+    s2, _ = colstats(4, x.t, x.ld, s1, 0, x.rows, c, [x.rows], alpha=1.0 / x.rows)   # centred second pass (tf.nn.moments)
     scale, shift, mean_inv = cx.scratch('bnsc', c), cx.scratch('bnsh', c), cx.scratch('bnmi', 2 * c)
     _call('tg_bn_finalize_f32', _p(s1), _p(s2), x.rows, c, _p(gamma), _p(beta), eps, _p(scale), _p(shift), _p(mean_inv), _p(mm), _p(mv),
           decay, 1 if (x.h * x.w > 1) else 0, cx.stream)

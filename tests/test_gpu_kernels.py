@@ -1,0 +1,190 @@
+"""GPU parity of the standalone kernels behind the C ABI: loss heads (+ feature-matching / pull-away), Adam / EMA,
+argmax one-hot, accuracy counter, Philox RNG statistics, segmented column statistics."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from tg import lib
+    lib.load()
+    return lib
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda()
+
+
+def st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def test_d_and_g_loss():
+    lib = _lib()
+    rng = np.random.default_rng(0)
+    n_r, n_f, n_u = 100, 100, 50
+    z = (rng.standard_normal((n_r + n_f + n_u, 1)) * 3).astype(np.float32)
+    lr, gr = T.bce_mean(z[:n_r], np.ones((n_r, 1), np.float32))
+    lf, gf = T.bce_mean(z[n_r:n_r + n_f], np.zeros((n_f, 1), np.float32))
+    lu, gu = T.bce_mean(z[n_r + n_f:], np.zeros((n_u, 1), np.float32))
+    zd, dz, loss = dev(z), torch.full((250, 32), 7.0, device='cuda'), torch.zeros(1, device='cuda')
+    lib.call('tg_d_loss_f32', lib.ptr(zd), 1, n_r, n_f, n_u, lib.ptr(dz), 32, lib.ptr(loss), st())
+    assert abs(loss.item() - (lr + 0.5 * lf + 0.5 * lu)) < 1e-5
+    g = dz.cpu().numpy()
+    np.testing.assert_allclose(g[:, 0:1], np.concatenate([gr, 0.5 * gf, 0.5 * gu]), rtol=1e-4, atol=1e-8)
+    assert (g[:, 1:] == 0).all()
+    lib.call('tg_g_loss_f32', lib.ptr(zd), 1, n_r, lib.ptr(dz), 32, lib.ptr(loss), st())
+    l1, g1 = T.bce_mean(z[:n_r], np.ones((n_r, 1), np.float32))
+    assert abs(loss.item() - 0.5 * l1) < 1e-5
+    np.testing.assert_allclose(dz.cpu().numpy()[:n_r, 0:1], 0.5 * g1, rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("with_rep", [True, False])
+def test_c_loss(with_rep):
+    lib = _lib()
+    rng = np.random.default_rng(1)
+    n_r, n_u, n_f = 50, 50, 100
+    lam1, lam2 = 0.3, 0.5
+    c_real, c_unl, c_rep, c_fake = [(rng.standard_normal((n, 10)) * 2).astype(np.float32) for n in (n_r, n_u, n_u, n_f)]
+    y_r = np.eye(10, dtype=np.float32)[rng.integers(0, 10, n_r)]
+    y_f = np.eye(10, dtype=np.float32)[rng.integers(0, 10, n_f)]
+    d_unl = (rng.standard_normal((n_u, 1)) * 2).astype(np.float32)
+    l_real, g_real = T.softmax_ce_mean(c_real, y_r)
+    l_fake, g_fake = T.softmax_ce_mean(c_fake, y_f)
+    l_unl, g_unl = T.c_unl_loss(c_unl, d_unl)
+    l_ent, g_ent = T.entropy(c_unl)
+    l_bal, g_bal = T.balance_entropy(c_unl)
+    l_mse, g_mu, g_mr = T.mse_mean(c_unl, c_rep)
+    if not with_rep:
+        l_mse, g_mu, g_mr = 0.0, 0 * g_mu, 0 * g_mr
+    ref = 0.005 * l_unl + l_real + 1e-6 * l_ent + 1e-3 * l_bal + lam1 * l_fake + lam2 * l_mse
+    parts = [c_real, c_unl] + ([c_rep] if with_rep else []) + [c_fake]
+    cl = np.zeros((sum(p.shape[0] for p in parts), 32), np.float32)
+    cl[:, :10] = np.concatenate(parts)
+    cld, dl, loss = dev(cl), torch.full(cl.shape, 7.0, device='cuda'), torch.zeros(1, device='cuda')
+    yr, yf, du, lam = dev(y_r), dev(y_f), dev(d_unl), dev(np.array([lam1, lam2]))
+    lib.call('tg_c_loss_f32', lib.ptr(cld), 32, n_r, n_u, n_u if with_rep else 0, n_f, lib.ptr(yr), lib.ptr(yf), lib.ptr(du), 1,
+             lib.ptr(lam), lib.ptr(dl), 32, lib.ptr(loss), st())
+    assert abs(loss.item() - ref) < 2e-5 * max(1, abs(ref))
+    g = dl.cpu().numpy()
+    gref = [g_real, 0.005 * g_unl + 1e-6 * g_ent + 1e-3 * g_bal + lam2 * g_mu] + ([lam2 * g_mr] if with_rep else []) + [lam1 * g_fake]
+    gref = np.concatenate(gref)
+    assert np.abs(g[:, :10] - gref).max() < 2e-4 * np.abs(gref).max()
+    assert (g[:, 10:] == 0).all()
+
+
+def test_feature_match_and_pull_away():
+    lib = _lib()
+    rng = np.random.default_rng(2)
+    ff, fu = rng.standard_normal((20, 128)).astype(np.float32), rng.standard_normal((30, 128)).astype(np.float32)
+    v, ga, gb = T.feature_match(ff, fu)
+    a, b = dev(ff), dev(fu)
+    da, db, loss = torch.zeros_like(a), torch.zeros_like(b), torch.zeros(1, device='cuda')
+    lib.call('tg_feature_match_f32', lib.ptr(a), 20, lib.ptr(b), 30, 128, lib.ptr(da), lib.ptr(db), lib.ptr(loss), st())
+    assert abs(loss.item() - v) < 1e-6
+    np.testing.assert_allclose(da.cpu().numpy(), ga, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(db.cpu().numpy(), gb, rtol=1e-5, atol=1e-9)
+    for masked, fn in ((1, T.pull_away_masked), (0, T.pull_away_unmasked)):
+        v, g = fn(ff.astype(np.float64))
+        scratch = torch.zeros(20 * 128 + 20 * 20 + 20, device='cuda')
+        lib.call('tg_pull_away_f32', lib.ptr(a), 20, 128, masked, lib.ptr(scratch), lib.ptr(da), lib.ptr(loss), st())
+        assert abs(loss.item() - v) < 1e-5 * max(1.0, abs(v))
+        assert np.abs(da.cpu().numpy() - g).max() < 1e-4 * np.abs(g).max() + 1e-9
+
+
+def test_adam_and_ema_bit_tight_on_identical_gradients():
+    lib = _lib()
+    rng = np.random.default_rng(3)
+    n = 10007                                 # odd: exercises the scalar tail
+    p0 = rng.standard_normal(n).astype(np.float32)
+    p, m, v = dev(p0), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    lr = dev(np.array([3e-4]))
+    step = torch.zeros(1, dtype=torch.int32, device='cuda')
+    shadow = dev(p0)
+    pr, mr, vr, sr = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32), p0.copy()
+    for t in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32)
+        g[::7] *= 1e-9                         # gradients around Adam's epsilon
+        g[::11] = 0
+        gd = dev(2 * g)                        # grad_scale 0.5 = mean over 2 replicas
+        lib.call('tg_adam_f32', lib.ptr(p), lib.ptr(gd), lib.ptr(m), lib.ptr(v), n, lib.ptr(lr), 0.5, 0.999, 1e-8, lib.ptr(step), 0.5, st())
+        lib.call('tg_ema_f32', lib.ptr(shadow), lib.ptr(p), n, 0.9999, st())
+        pr, mr, vr = T.adam_update(pr, g, mr, vr, t, 3e-4, 0.5)
+        sr = T.ema_update(sr, pr)
+    assert step.item() == 3
+    np.testing.assert_allclose(m.cpu().numpy(), mr, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(v.cpu().numpy(), vr, rtol=1e-6, atol=1e-20)
+    assert np.abs(p.cpu().numpy() - pr).max() <= 3e-4 * 3e-6 + 2e-7 * np.abs(pr).max()
+    np.testing.assert_allclose(shadow.cpu().numpy(), sr, rtol=1e-6, atol=1e-7)
+
+
+def test_argmax_onehot_and_accuracy():
+    lib = _lib()
+    rng = np.random.default_rng(4)
+    lg = rng.standard_normal((77, 10)).astype(np.float32)
+    lg[5, 3] = lg[5, 7] = 9.0                                   # tie: first index wins (tf.argmax)
+    lp = np.zeros((77, 32), np.float32)
+    lp[:, :10] = lg
+    ld, out = dev(lp), torch.zeros(77 * 10, device='cuda')
+    lib.call('tg_argmax_onehot_f32', lib.ptr(ld), 32, 77, 10, lib.ptr(out), st())
+    np.testing.assert_array_equal(out.cpu().numpy().reshape(77, 10), T.argmax_onehot(lg))
+    labels = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 77)]
+    cnt, lab = torch.zeros(2, device='cuda'), dev(labels)
+    for _ in range(2):
+        lib.call('tg_accuracy_count_f32', lib.ptr(ld), 32, lib.ptr(lab), 77, 10, lib.ptr(cnt), st())
+    correct = (lg.argmax(1) == labels.argmax(1)).sum()
+    assert tuple(cnt.cpu().numpy()) == (2.0 * correct, 154.0)
+
+
+def test_colstats_segments_ragged():
+    lib = _lib()
+    rng = np.random.default_rng(5)
+    segs = [300, 7, 1025]
+    rows, c, ld = sum(segs), 10, 32
+    a = np.zeros((rows, ld), np.float32)
+    a[:, :c] = rng.standard_normal((rows, c))
+    y = np.zeros((rows, ld), np.float32)
+    y[:, :c] = rng.standard_normal((rows, c))
+    ad, yd = dev(a), dev(y)
+    wsn = lib.call('tg_colstats_workspace_floats', rows, len(segs), c)
+    work, s1, s2 = torch.zeros(wsn, device='cuda'), torch.zeros(3 * c, device='cuda'), torch.zeros(3 * c, device='cuda')
+    sa = (C.c_int32 * 3)(*segs)
+    off = np.cumsum([0] + segs)
+    sl = [slice(off[i], off[i + 1]) for i in range(3)]
+    lib.call('tg_colstats_f32', 1, lib.ptr(ad), ld, None, 0, rows, c, sa, 3, 0, 0.0, lib.ptr(work), lib.ptr(s1), lib.ptr(s2), st())
+    np.testing.assert_allclose(s1.cpu().numpy().reshape(3, c), [a[s, :c].sum(0) for s in sl], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(s2.cpu().numpy().reshape(3, c), [(a[s, :c] ** 2).sum(0) for s in sl], rtol=1e-4, atol=1e-4)
+    lib.call('tg_colstats_f32', 2, lib.ptr(ad), ld, lib.ptr(yd), ld, rows, c, sa, 3, 1, 0.2, lib.ptr(work), lib.ptr(s1), None, st())
+    ref = [(a[s, :c] * np.where(y[s, :c] > 0, 1.0, 0.2)).sum(0) for s in sl]
+    np.testing.assert_allclose(s1.cpu().numpy().reshape(3, c), ref, rtol=1e-4, atol=1e-4)
+    with pytest.raises(lib.TgError, match="segments sum"):
+        lib.call('tg_colstats_f32', 0, lib.ptr(ad), ld, None, 0, rows + 1, c, sa, 3, 0, 0.0, lib.ptr(work), lib.ptr(s1), None, st())
+
+
+def test_philox_streams_are_distinct_and_well_distributed():
+    lib = _lib()
+    n = 1 << 20
+    state = torch.tensor([1234, 0], dtype=torch.int64, device='cuda')
+    u, u2, mask, nrm = [torch.zeros(n, device='cuda') for _ in range(4)]
+    lib.call('tg_rng_uniform_f32', lib.ptr(u), n, -1.0, 1.0, lib.ptr(state), 1, st())
+    lib.call('tg_rng_uniform_f32', lib.ptr(u2), n, -1.0, 1.0, lib.ptr(state), 2, st())
+    lib.call('tg_rng_keep_mask_f32', lib.ptr(mask), n, 0.8, lib.ptr(state), 3, st())
+    lib.call('tg_rng_normal_f32', lib.ptr(nrm), n, 0.15, lib.ptr(state), 4, st())
+    un, un2, mk, nm = u.cpu().numpy(), u2.cpu().numpy(), mask.cpu().numpy(), nrm.cpu().numpy()
+    assert -1 <= un.min() and un.max() < 1 and abs(un.mean()) < 5e-3 and abs(un.var() - 1 / 3) < 5e-3
+    assert abs(np.corrcoef(un, un2)[0, 1]) < 5e-3
+    assert set(np.unique(mk)) == {0.0, 1.0} and abs(mk.mean() - 0.8) < 2e-3
+    assert abs(nm.mean()) < 1e-3 and abs(nm.std() - 0.15) < 1e-3
+    lib.call('tg_rng_advance', lib.ptr(state), st())           # a graph replay draws new numbers
+    lib.call('tg_rng_uniform_f32', lib.ptr(u2), n, -1.0, 1.0, lib.ptr(state), 1, st())
+    assert abs(np.corrcoef(un, u2.cpu().numpy())[0, 1]) < 5e-3
+    oh = torch.zeros(1000 * 10, device='cuda')
+    lib.call('tg_rng_onehot_f32', lib.ptr(oh), 1000, 10, lib.ptr(state), 5, st())
+    o = oh.cpu().numpy().reshape(1000, 10)
+    assert (o.sum(1) == 1).all() and o.sum(0).min() > 50

@@ -226,7 +226,7 @@ def test_adam_is_tf_form():
         mm = 0.5 * mm + 0.5 * g
         vv = 0.999 * vv + 0.001 * g * g
         q = q - 3e-4 * np.sqrt(1 - 0.999 ** step) / (1 - 0.5 ** step) * mm / (np.sqrt(vv) + 1e-8)
-    np.testing.assert_allclose(p, q, rtol=1e-14)
+    np.testing.assert_allclose(p, q, rtol=1e-12)
 
 
 def test_dropout_and_concat():
