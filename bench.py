@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Triple-GAN training throughput on MI355X: images/sec of the full D+G+C step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one iteration of Training/Train_goodGAN.py:266-276 (D-update, G-update, C-update + EMA) on the CIFAR-10
+config of the reference (32x32x3, B_G/L_C/U_C/L_D/U_D = 100/50/50/20/80, fp32), synthetic class-prototype batches
+already resident in HBM, random-init weights, synthetic orthogonal ZCA.  images/sec = BATCH_SIZE(100) * steps/sec *
+replicas (weak scaling: every replica runs the single-GPU batch; gradients are sum-all-reduced over RCCL).
+
+The JSON line also carries
+  roofline     — the MFMA implicit-GEMM kernel class (conv fwd / dgrad / deconv / dense): algorithmic FLOPs of its launches
+                 in one iteration / their summed HIP-event durations, measured in an instrumented eager pass on the
+                 launch stream right after the timed region (the timed region itself replays hipGraphs, whose inner
+                 kernels cannot be bracketed by events); peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).
+  cpu_baseline — the NumPy oracle (oracle/step_cifar10.py, a port: TF1 is not installable) timed on this host's cores
+                 for one iteration of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "tensorflow-implementation-of-triple-gan_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+SIZES = dict(B_G=100, L_C=50, U_C=50, L_D=20, U_D=80)
+
+
+def algorithmic_flops(s=SIZES):
+    """SURVEY §8d counting rule: conv/deconv/dense forward = 2*MACs, backward-data = backward-weight = forward, no
+    data-gradient for a network's first layer unless its input needs one; only what each solver run executes."""
+    mf = lambda h, k, ci, co: 2.0 * h * h * k * k * ci * co
+    c_layers = [mf(32, 3, 3, 128), mf(32, 3, 128, 128), mf(32, 3, 128, 128), mf(16, 3, 128, 256), mf(16, 3, 256, 256),
+                mf(16, 3, 256, 256), mf(6, 3, 256, 512), mf(6, 1, 512, 256), mf(6, 1, 256, 128), 2.0 * 128 * 10]
+    d_layers = [mf(32, 3, 13, 32), mf(16, 3, 42, 32), mf(16, 3, 42, 64), mf(8, 3, 74, 64), mf(8, 3, 74, 128), mf(8, 3, 138, 128),
+                2.0 * 138]
+    g_layers = [2.0 * 110 * 8192, 2.0 * 4 * 4 * 25 * 522 * 256, 2.0 * 8 * 8 * 25 * 266 * 128, 2.0 * 16 * 16 * 25 * 138 * 3]
+    zca = 2.0 * 3072 * 3072
+    C, D, Gn = sum(c_layers), sum(d_layers), sum(g_layers)
+    n_d = s['L_D'] + s['U_D'] + s['B_G'] + s['U_C']
+    n_cd = s['U_C'] + s['U_D']
+    n_c = s['L_C'] + 2 * s['U_C'] + s['B_G']
+    fwd = {
+        'D': s['B_G'] * Gn + n_cd * (zca + C) + n_d * D,
+        'G': s['B_G'] * (Gn + D),
+        'C': s['B_G'] * Gn + (s['L_C'] + s['U_C'] + s['B_G']) * zca + n_c * C + s['U_C'] * D,
+    }
+    dgrad = {'D': n_d * (D - d_layers[0]), 'G': s['B_G'] * (D + Gn - g_layers[0]), 'C': n_c * (C - c_layers[0])}
+    wgrad = {'D': n_d * D, 'G': s['B_G'] * Gn, 'C': n_c * C}
+    igemm = sum(fwd.values()) + sum(dgrad.values())
+    wg = sum(wgrad.values())
+    conv3x3 = n_c * sum(c_layers[:7])     # classifier 3x3 convolutions, forward
+    return dict(total=igemm + wg, igemm=igemm, wgrad=wg, c_conv3x3_fwd=conv3x3)
+
+
+def make_config(rank):
+    from config import Config
+    from oracle.step_cifar10 import synth_zca      # synthetic ZCA constants only (data generation, not compute)
+
+    class TempConfig(Config):
+        NAME = "Good_GAN"
+        DATA_NAME = "cifar10"
+        DATA_DIR = "/nonexistent"
+        NUM_LABEL = 4000
+        BATCH_SIZE_G = SIZES['B_G']
+        BATCH_SIZE_L_C = SIZES['L_C']
+        BATCH_SIZE_U_C = SIZES['U_C']
+        BATCH_SIZE_L_D = SIZES['L_D']
+        BATCH_SIZE_U_D = SIZES['U_D']
+        BATCH_SIZE = SIZES['B_G']
+        IMAGE_HEIGHT, IMAGE_WIDTH, CHANNEL = 32, 32, 3
+        FAKE_G_LAMBDA = 0.3
+        Z_DIM = 100
+        NUM_CLASSES = 10
+        LEARNING_RATE = 3e-4
+        CLA_LEARNINIG_RATE = 3e-3
+        EPOCHS = 1
+        TRAIN_SIZE = 56000
+        SUMMARY = False
+        USE_HIP_GRAPH = True
+        SEED = 0
+        ZCA = synth_zca()
+        RANK = rank
+
+    return TempConfig()
+
+
+def cpu_baseline_one_iteration():
+    """the oracle as the CPU baseline ('port'): one iteration = 100 nominal images."""
+    from oracle import step_cifar10 as S
+    P = S.init_params(0)
+    st = S.new_state(P)
+    zca = S.synth_zca()
+    batch, rnd = S.synth_batch(1), S.synth_rnd(2)
+    hyper = dict(lr=3e-4, cla_lr=3e-3, beta1=0.5, lambda_1=0.3, lambda_2=0.5)
+    t0 = time.perf_counter()
+    S.train_step(st, batch, rnd, hyper, zca)
+    dt = time.perf_counter() - t0
+    return dict(value=SIZES['B_G'] / dt, unit="images/sec", cores=os.cpu_count(), kind="port",
+                sample="1 iteration (100 nominal images, 1464 GFLOP) of the same CIFAR-10 workload, NumPy/BLAS fp32 oracle, %.1f s" % dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying hipGraphs')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--prof-iters', type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    from tg import dist as tgdist
+    from tg import lib
+    from Training.Train_goodGAN import Train
+    from Model.Good_GAN_cifar10 import Good_GAN_cifar10
+    from Input_Pipeline.syntheticDataset import syntheticDataset
+
+    world, rank, local = tgdist.env_world()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    cfg = make_config(rank)
+    cfg.USE_HIP_GRAPH = not args.no_graph
+    tr = Train(cfg, None, None)
+    tr._build_train_graph(Good_GAN_cifar10)
+    tr.set_hyper(lambda_1=cfg.FAKE_G_LAMBDA, lambda_2=0.5)       # the late-training schedule: every loss term active
+    cx = tr.cx
+
+    # synthetic batches, resident in HBM before the timed region (per-rank seed: SURVEY §8d)
+    ds = syntheticDataset(None, cfg, cfg.NUM_LABEL, 'train', seed=1234 + rank)
+    pool = []
+    for _ in range(4):
+        b = ds._next()
+        pool.append({k: cx.from_numpy(v) for k, v in b.items()})
+
+    def step(i):
+        tr.feed(pool[i % len(pool)])
+        tr.sample_latent()
+        tr.train_iteration()
+
+    for i in range(max(args.warmup, 2)):          # >= 2: first call allocates eagerly, second captures the graphs
+        step(i)
+    torch.cuda.synchronize()
+    tgdist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+    tgdist.barrier()
+    dt = tgdist.max_over_ranks(dt_local, cx.device)
+    losses = tr.losses()
+
+    # ---- instrumented eager pass: per-kernel-class HIP-event timing on the launch stream
+    fl = algorithmic_flops()
+    lib.call('tg_prof_reset')
+    lib.call('tg_prof_enable', 1)
+    for i in range(args.prof_iters):
+        tr.feed(pool[i % len(pool)])
+        tr.sample_latent()
+        tr.train_iteration(use_graph=False)
+    torch.cuda.synchronize()
+    lib.call('tg_prof_enable', 0)
+    import ctypes as C
+    classes = {}
+    for cls in range(lib.call('tg_prof_num_classes')):
+        ms, n, f, b = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        lib.call('tg_prof_collect', cls, C.byref(ms), C.byref(n), C.byref(f), C.byref(b))
+        name = lib.load().tg_prof_class_name(cls).decode()
+        classes[name] = dict(ms_per_iter=ms.value / args.prof_iters, launches_per_iter=n.value / args.prof_iters,
+                             executed_gflop_per_iter=f.value / args.prof_iters / 1e9, gbytes_per_iter=b.value / args.prof_iters / 1e9)
+    if os.environ.get('TG_PROF_DUMP'):
+        lib.call('tg_prof_dump', os.environ['TG_PROF_DUMP'].encode())
+    lib.call('tg_prof_reset')
+    ig = classes['igemm_f32']
+    achieved = fl['igemm'] / (ig['ms_per_iter'] * 1e-3) / 1e12
+    roofline = dict(bound="mfma", kernel="igemm_f32_kernel (conv fwd/dgrad, deconv, dense)", achieved=round(achieved, 2),
+                    peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                    launches_per_step=ig['launches_per_iter'], avg_launch_ms=round(ig['ms_per_iter'] / max(ig['launches_per_iter'], 1), 5),
+                    algorithmic_gflop_per_step=round(fl['igemm'] / 1e9, 1),
+                    wgrad_f32=dict(achieved=round(fl['wgrad'] / (classes['wgrad_f32']['ms_per_iter'] * 1e-3) / 1e12, 2),
+                                   algorithmic_gflop_per_step=round(fl['wgrad'] / 1e9, 1)),
+                    class_ms_per_step={k: round(v['ms_per_iter'], 3) for k, v in classes.items()})
+
+    if rank == 0:
+        out = {
+            "metric": "Triple-GAN train images/sec (G+C+D step) CIFAR-10 32x32 bs=100",
+            "value": round(args.steps * SIZES['B_G'] * world / dt, 2),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "CIFAR-10 32x32x3, 4000 labelled, bs=100 fp32 (B_G/L_C/U_C/L_D/U_D=100/50/50/20/80), "
+                                   "Good_GAN_cifar10 D+G+C step", "global_batch": SIZES['B_G'] * world, "parallelism": "dp%d" % world,
+                       "hip_graph": bool(cfg.USE_HIP_GRAPH), "algorithmic_gflop_per_step": round(fl['total'] / 1e9, 1),
+                       "step_tflops": round(fl['total'] / (dt / args.steps) / 1e12, 2), "losses_d_g_c": [round(v, 4) for v in losses]},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_one_iteration()
+        print(json.dumps(out), flush=True)
+    tgdist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

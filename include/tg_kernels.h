@@ -57,6 +57,8 @@ const char* tg_prof_class_name(int cls);
 /* host outputs: total milliseconds, launch count, algorithmic flops and bytes of class `cls`
  * since the last reset; synchronises the recorded events. */
 int tg_prof_collect(int cls, double* ms, int64_t* launches, double* flops, double* bytes);
+/* one CSV row per recorded launch (class, ms, executed GFLOP, GB, geometry) — host path. */
+int tg_prof_dump(const char* path);
 
 /* ---- implicit-GEMM convolution family (MFMA v_mfma_f32_32x32x2_f32) ----------------------------- */
 #define TG_MAX_TAPS 25
@@ -83,6 +85,10 @@ typedef struct tg_igemm_desc {
  * tf.matmul / tf.layers.dense (Model/nn.py:553, Model/modle_base.py:40) and the ZCA matmul
  * (Model/Good_GAN_cifar10.py:296).  bias may be NULL. */
 int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* stream);
+/* up to 4 sub-problems in ONE launch (the output parities of a stride-2 transposed conv / strided-conv input-gradient):
+ * same buffers, M, N and gathered tensor; each descriptor brings its own taps and output offsets. */
+int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,
+                       void* stream);
 
 /* filter gradient, split over `n_split` pixel ranges:
  * slab[s][t][c][n] = sum_{p in split s} in[pix(p,t),c] * dout[p,n]   (c < ld_in, n < c_out).

@@ -16,6 +16,7 @@
 //  * register-staged double buffering: global loads of tile i+1 are issued before the 64 MFMAs of tile i and
 //    written to the other LDS buffer after them; one barrier per K-tile; 2 workgroups per CU (76 KB LDS each).
 //  * NHWC gathers are 16 B per lane, 128 B contiguous per 8 lanes; out-of-image taps load nothing.
+#include <cstdio>
 #include "tg_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -26,14 +27,30 @@ namespace {
 constexpr int BK = 32;    // reduction depth per LDS tile
 constexpr int LDT = 36;   // padded LDS row stride (floats)
 
+constexpr int MAX_SUB = 4;   // sub-problems per launch (the 4 output parities of a stride-2 transposed conv / dgrad)
+
+// kernel-side view of one tg_igemm_desc: tap tables repacked to one dword per tap so that the (block-uniform) tap
+// lookup is a scalar s_load_dword — int8/int16 arrays indexed dynamically compile to VECTOR byte loads plus a
+// vmcnt wait at the top of every K-tile.
+struct SubDesc {
+  int32_t h_v, w_v, s_y, s_x, h_out, w_out, ld_out, os_y, os_x, oo_y, oo_x, n_store, n_taps, act;
+  float alpha;
+  int32_t taps[TG_MAX_TAPS];     // (tapw << 16) | ((dy & 0xff) << 8) | (dx & 0xff)
+};
+
 struct IgemmParams {
   const float* in;
   const float* w;
   const float* bias;
   float* out;
-  tg_igemm_desc d;
-  int M, n_tiles;
+  SubDesc d[MAX_SUB];
+  int64_t w_sn, w_st;
+  int n_img, h_in, w_in, ld_in, c_out;
+  int n_sub, M, m_tiles, n_tiles;
+  uint32_t in_bytes;
 };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   switch (act) {
@@ -44,6 +61,13 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
     case TG_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(__expf(v));
     default: return v;
   }
+}
+
+// XCD-aware bijective remap (8 XCDs, blocks b and b+8 share one): every XCD works on a contiguous run of logical tiles,
+// so the n-tiles that re-read one A tile and neighbouring m-tiles (shared halo rows) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -59,9 +83,12 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   int* t_x = t_y + BM;
   int* t_out = t_x + BM;
 
-  const tg_igemm_desc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nt = blockIdx.x % p.n_tiles, mt = blockIdx.x / p.n_tiles;
+  const int per_sub = p.m_tiles * p.n_tiles;
+  const int lid = xcd_remap(blockIdx.x, per_sub * p.n_sub);
+  const int sub = lid / per_sub, rem_id = lid - sub * per_sub;
+  const SubDesc& d = p.d[sub];
+  const int nt = rem_id % p.n_tiles, mt = rem_id / p.n_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
 
   if (tid < BM) {
@@ -71,7 +98,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       int hw = d.h_v * d.w_v;
       int img = m / hw, rem = m - img * hw;
       int vy = rem / d.w_v, vx = rem - vy * d.w_v;
-      base = img * d.h_in * d.w_in * d.ld_in;
+      base = img * p.h_in * p.w_in * p.ld_in;
       y0 = vy * d.s_y;
       x0 = vx * d.s_x;
       oo = ((img * d.h_out + vy * d.os_y + d.oo_y) * d.w_out + vx * d.os_x + d.oo_x) * d.ld_out;
@@ -89,23 +116,30 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   }
   const float* wrow[BR];
 #pragma unroll
-  for (int j = 0; j < BR; ++j) wrow[j] = p.w + (int64_t)(n0 + lrow + 32 * j) * d.w_sn + seg * 4;
+  for (int j = 0; j < BR; ++j) wrow[j] = p.w + (int64_t)(n0 + lrow + 32 * j) * p.w_sn + seg * 4;
 
-  f32x4 ra[AR], rb[BR];
-  const int cchunks = d.ld_in / BK;
+  // Gathered operand through a buffer descriptor: an out-of-image tap gets byte offset 0xFFFFFFF0, the hardware range
+  // check returns zeros — no branch and no select, so the loads stay in flight behind the MFMAs (a per-element
+  // `ok ? load : 0` makes hipcc branch around every load and wait vmcnt(0) before the MFMA block).
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+
+  u32x4 ra[AR];
+  f32x4 rb[BR];
+  const int cchunks = p.ld_in / BK;
   const int nk = d.n_taps * cchunks;
+  const int h_in = p.h_in, w_in = p.w_in, ld_in = p.ld_in;
 
   auto gload = [&](int tap, int c0) {
-    const int dy = d.dy[tap], dx = d.dx[tap];
+    const int tp = d.taps[tap];
+    const int dy = (int)(int8_t)(tp >> 8), dx = (int)(int8_t)tp;
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
-      int iy = ay[j] + dy, ix = ax[j] + dx;
-      bool ok = (unsigned)iy < (unsigned)d.h_in && (unsigned)ix < (unsigned)d.w_in;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(p.in + (abase[j] + (iy * d.w_in + ix) * d.ld_in + c0));
-      ra[j] = v;
+      const int iy = ay[j] + dy, ix = ax[j] + dx;
+      const bool ok = (unsigned)iy < (unsigned)h_in && (unsigned)ix < (unsigned)w_in;
+      const uint32_t off = ok ? (uint32_t)(abase[j] + (iy * w_in + ix) * ld_in + c0) * 4u : 0xFFFFFFF0u;
+      ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
     }
-    const int64_t wo = (int64_t)d.tapw[tap] * d.w_st + c0;
+    const int64_t wo = (int64_t)(tp >> 16) * p.w_st + c0;
 #pragma unroll
     for (int j = 0; j < BR; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + wo);
   };
@@ -113,7 +147,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     float* a = As + buf * BM * LDT + lrow * LDT + seg * 4;
     float* b = Bs + buf * BN * LDT + lrow * LDT + seg * 4;
 #pragma unroll
-    for (int j = 0; j < AR; ++j) *reinterpret_cast<f32x4*>(a + 32 * j * LDT) = ra[j];
+    for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4*>(a + 32 * j * LDT) = ra[j];
 #pragma unroll
     for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(b + 32 * j * LDT) = rb[j];
   };
@@ -138,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     const bool more = it + 1 < nk;
     if (more) {
       c0 += BK;
-      if (c0 == d.ld_in) { c0 = 0; ++tap; }
+      if (c0 == ld_in) { c0 = 0; ++tap; }
       gload(tap, c0);
     }
     const float* A = As + buf * BM * LDT + wm0 * LDT + frag;
@@ -367,28 +401,65 @@ int check_desc(const tg_igemm_desc* d) {
 
 }  // namespace
 
-extern "C" int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* stream) {
-  int rc = check_desc(d);
-  if (rc != TG_OK) return rc;
+template <int BM, int BN, int WM_, int WN_>
+static void launch_igemm(IgemmParams& p, hipStream_t s) {
+  p.m_tiles = (p.M + BM - 1) / BM;
+  p.n_tiles = p.c_out / BN;
+  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_>), dim3(p.m_tiles * p.n_tiles * p.n_sub), dim3(256), 0, s, p);
+}
+
+extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,
+                                  void* stream) {
+  TG_REQUIRE(descs && n_desc >= 1 && n_desc <= MAX_SUB, "igemm: n_desc=%d out of range", n_desc);
   TG_REQUIRE(in && w && out, "igemm: null buffer");
-  IgemmParams p{in, w, bias, out, *d, 0, 0};
-  p.M = d->n_img * d->h_v * d->w_v;
-  const double flops = 2.0 * p.M * d->c_out * d->n_taps * d->ld_in;
-  const double bytes = 4.0 * ((double)p.M * d->ld_in + (double)p.M * d->n_store + (double)d->c_out * d->n_taps * d->ld_in);
-  tg::ProfScope prof(tg::PC_IGEMM, flops, bytes, tg::as_stream(stream));
-  const int m_tiles = (p.M + 127) / 128;
-  if (d->c_out % 128 == 0) {
-    p.n_tiles = d->c_out / 128;
-    hipLaunchKernelGGL((igemm_f32_kernel<128, 128, 2, 2>), dim3(m_tiles * p.n_tiles), dim3(256), 0, tg::as_stream(stream), p);
-  } else if (d->c_out % 64 == 0) {
-    p.n_tiles = d->c_out / 64;
-    hipLaunchKernelGGL((igemm_f32_kernel<128, 64, 2, 2>), dim3(m_tiles * p.n_tiles), dim3(256), 0, tg::as_stream(stream), p);
-  } else {
-    p.n_tiles = d->c_out / 32;
-    hipLaunchKernelGGL((igemm_f32_kernel<128, 32, 4, 1>), dim3(m_tiles * p.n_tiles), dim3(256), 0, tg::as_stream(stream), p);
+  IgemmParams p;
+  p.in = in; p.w = w; p.bias = bias; p.out = out; p.n_sub = n_desc;
+  const tg_igemm_desc* d = &descs[0];
+  for (int i = 0; i < n_desc; ++i) {
+    int rc = check_desc(&descs[i]);
+    if (rc != TG_OK) return rc;
+    const tg_igemm_desc& e = descs[i];
+    TG_REQUIRE(e.n_img == d->n_img && e.h_v == d->h_v && e.w_v == d->w_v && e.c_out == d->c_out && e.ld_in == d->ld_in && e.h_in == d->h_in &&
+               e.w_in == d->w_in && e.w_sn == d->w_sn && e.w_st == d->w_st, "igemm: sub-problem %d differs in M / N / gathered tensor / filter strides", i);
+    SubDesc& k = p.d[i];
+    k.h_v = e.h_v; k.w_v = e.w_v; k.s_y = e.s_y; k.s_x = e.s_x; k.h_out = e.h_out; k.w_out = e.w_out; k.ld_out = e.ld_out;
+    k.os_y = e.os_y; k.os_x = e.os_x; k.oo_y = e.oo_y; k.oo_x = e.oo_x; k.n_store = e.n_store; k.n_taps = e.n_taps; k.act = e.act;
+    k.alpha = e.alpha;
+    for (int t = 0; t < e.n_taps; ++t)
+      k.taps[t] = ((int32_t)e.tapw[t] << 16) | (((int32_t)e.dy[t] & 0xff) << 8) | ((int32_t)e.dx[t] & 0xff);
   }
+  p.w_sn = d->w_sn; p.w_st = d->w_st;
+  p.n_img = d->n_img; p.h_in = d->h_in; p.w_in = d->w_in; p.ld_in = d->ld_in; p.c_out = d->c_out;
+  p.M = d->n_img * d->h_v * d->w_v;
+  const int64_t in_bytes = (int64_t)d->n_img * d->h_in * d->w_in * d->ld_in * 4;
+  TG_REQUIRE(in_bytes < 0xFFFFFFF0LL, "igemm: gathered tensor exceeds the 4 GiB buffer-descriptor range");
+  p.in_bytes = (uint32_t)in_bytes;
+  double taps = 0;
+  for (int i = 0; i < n_desc; ++i) taps += descs[i].n_taps;
+  const double flops = 2.0 * p.M * d->c_out * taps * d->ld_in;
+  const double bytes = 4.0 * ((double)p.M * d->ld_in + (double)p.M * d->n_store * n_desc + (double)d->c_out * taps * d->ld_in);
+  char desc[96];
+  snprintf(desc, sizeof(desc), "M=%dx%d N=%d K=%gx%d in=%dx%d s=%d os=%d", n_desc, p.M, d->c_out, taps, d->ld_in, d->h_in, d->w_in, d->s_y, d->os_y);
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_IGEMM, flops, bytes, s, desc);
+  // tile choice: the largest tile that still gives >= ~1.5 workgroups per CU (2 are resident); small problems (generator,
+  // discriminator tail, ZCA) fall back to 64-row / 64-column tiles for parallelism.
+  int bn = d->c_out % 128 == 0 ? 128 : (d->c_out % 64 == 0 ? 64 : 32);
+  int bm = 128;
+  auto blocks = [&](int m, int n) { return (int64_t)n_desc * ((p.M + m - 1) / m) * (d->c_out / n); };
+  if (blocks(bm, bn) < 384 && bn == 128) bn = 64;
+  if (blocks(bm, bn) < 384 && bn >= 64) bm = 64;
+  if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2>(p, s);
+  else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2>(p, s);
+  else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2>(p, s);
+  else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2>(p, s);
+  else launch_igemm<128, 32, 4, 1>(p, s);
   TG_CHECK_LAUNCH("igemm_f32_kernel");
   return TG_OK;
+}
+
+extern "C" int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* stream) {
+  return tg_igemm_multi_f32(d, 1, in, w, bias, out, stream);
 }
 
 template <int CT, int NT, int WC, int WN, int WK>
@@ -410,7 +481,9 @@ extern "C" int tg_wgrad_f32(const tg_igemm_desc* d, const float* in, const float
   p.px_per_split = (((p.M + n_split - 1) / n_split) + BK - 1) / BK * BK;
   const double flops = 2.0 * p.M * d->c_out * d->n_taps * d->ld_in;
   const double bytes = 4.0 * ((double)p.M * d->ld_in + (double)p.M * d->c_out + (double)n_split * d->c_out * d->n_taps * d->ld_in);
-  tg::ProfScope prof(tg::PC_WGRAD, flops, bytes, tg::as_stream(stream));
+  char desc[96];
+  snprintf(desc, sizeof(desc), "M=%d N=%d K=%dx%d in=%dx%d s=%d split=%d", p.M, d->c_out, d->n_taps, d->ld_in, d->h_in, d->w_in, d->s_y, n_split);
+  tg::ProfScope prof(tg::PC_WGRAD, flops, bytes, tg::as_stream(stream), desc);
   hipStream_t s = tg::as_stream(stream);
   const int ct = d->ld_in % 128 == 0 ? 128 : (d->ld_in % 64 == 0 ? 64 : 32);
   const int nt = d->c_out % 128 == 0 ? 128 : (d->c_out % 64 == 0 ? 64 : 32);

@@ -23,7 +23,7 @@ int hip_fail(hipError_t e, const char* what) {
 
 static const char* kClassNames[PC_COUNT] = {"igemm_f32", "wgrad_f32", "prep", "norm", "elementwise", "loss", "optim"};
 
-struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; char desc[96]; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -36,10 +36,11 @@ static hipEvent_t get_event() {
   return e;
 }
 
-ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t s) : idx(-1), stream(s) {
+ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t s, const char* desc) : idx(-1), stream(s) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_mu);
-  ProfRec r{get_event(), get_event(), cls, flops, bytes};
+  ProfRec r{get_event(), get_event(), cls, flops, bytes, {0}};
+  if (desc) snprintf(r.desc, sizeof(r.desc), "%s", desc);
   (void)hipEventRecord(r.a, s);
   idx = (int)g_recs.size();
   g_recs.push_back(r);
@@ -105,6 +106,20 @@ int tg_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
   g_recs.clear();
+  return TG_OK;
+}
+
+int tg_prof_dump(const char* path) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  FILE* f = fopen(path, "w");
+  if (!f) { set_error("tg_prof_dump: cannot open %s", path); return TG_ERR_INVALID; }
+  fprintf(f, "class,ms,gflop,gbytes,desc\n");
+  for (auto& r : g_recs) {
+    float dt = 0;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&dt, r.a, r.b) != hipSuccess) dt = -1;
+    fprintf(f, "%s,%.5f,%.4f,%.5f,%s\n", kClassNames[r.cls], dt, r.flops / 1e9, r.bytes / 1e9, r.desc);
+  }
+  fclose(f);
   return TG_OK;
 }
 

@@ -22,7 +22,7 @@ enum ProfClass {
 };
 
 struct ProfScope {
-  ProfScope(int cls, double flops, double bytes, hipStream_t s);
+  ProfScope(int cls, double flops, double bytes, hipStream_t s, const char* desc = nullptr);
   ~ProfScope();
   int idx;
   hipStream_t stream;

@@ -43,7 +43,7 @@ def _ctype_of(decl):
     if typ.endswith("*"):
         base = typ.replace("const", "").replace("*", "").strip()
         if base == "tg_igemm_desc":
-            return C.POINTER(IgemmDesc)
+            return C.c_void_p if name == "descs" else C.POINTER(IgemmDesc)
         if typ.count("*") == 2:
             return C.POINTER(C.c_void_p)
         if name in HOST_INT_ARRAYS:
@@ -52,6 +52,8 @@ def _ctype_of(decl):
             return C.POINTER(C.c_double)
         if name == "launches":
             return C.POINTER(C.c_int64)
+        if name == "path":
+            return C.c_char_p
         return C.c_void_p
     return _SCALARS[typ]
 
@@ -83,6 +85,9 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise TgError("HIP extension missing: %s (run __graft_entry__.build() / make -C csrc)" % LIB_PATH)
+    # torch first: it bundles its own libamdhip64; loading ours afterwards binds libtg_hip.so to that SAME runtime
+    # (device buffers and streams are torch's).  The other order leaves two HIP runtimes in the process.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in parse_header().items():
         fn = getattr(lib, name)          # AttributeError if the header and the .so drift apart
@@ -111,3 +116,9 @@ def ptr(t):
 def cur_stream():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def desc_array(descs):
+    """contiguous ctypes array of descriptors for tg_igemm_multi_f32."""
+    arr = (IgemmDesc * len(descs))(*descs)
+    return arr

@@ -135,8 +135,8 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
                 _call('tg_wn_bwd_f32', _p(dw), _p(kernel), _p(wn[0]), t * c_in, c_out, _p(kernel_grad), _p(wn[1]), _p(coef), cx.stream)
         if needs_x:
             gx = cx.grad_of(x)
-            for dd in geom.conv_dgrad(x.n, x.h, x.w, ci_p, co_p, k, stride, padding, ld_out=gx.ld, n_store=ci_p):
-                _call('tg_igemm_f32', dd, _p(dpre), _p(w_hwio), None, gx.ptr, cx.stream)
+            dds = lib.desc_array(geom.conv_dgrad(x.n, x.h, x.w, ci_p, co_p, k, stride, padding, ld_out=gx.ld, n_store=ci_p))
+            _call('tg_igemm_multi_f32', C.cast(dds, C.c_void_p), len(dds), _p(dpre), _p(w_hwio), None, gx.ptr, cx.stream)
 
     cx.record(bwd)
     return y
@@ -155,8 +155,8 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
     _call('tg_filter_prep_f32', _p(kernel), None, 25, c_out, c_in, co_p, ci_p, _p(w_pad), _p(w_tr), co_p, ci_p * co_p, cx.stream)
     ld_out = c_out if narrow_out else co_p
     y = cx.new_act(x.n, 2 * x.h, 2 * x.w, c_out, ld_out, requires_grad=needs_w or needs_x)
-    for d in geom.deconv_fwd(x.n, x.h, x.w, ci_p, co_p, ld_out=ld_out, n_store=c_out, act=act):
-        _call('tg_igemm_f32', d, x.ptr, _p(w_pad), _p(bias), y.ptr, cx.stream)
+    dds = lib.desc_array(geom.deconv_fwd(x.n, x.h, x.w, ci_p, co_p, ld_out=ld_out, n_store=c_out, act=act))
+    _call('tg_igemm_multi_f32', C.cast(dds, C.c_void_p), len(dds), x.ptr, _p(w_pad), _p(bias), y.ptr, cx.stream)
     if not (needs_w or needs_x):
         return y
 
