@@ -17,6 +17,7 @@
 //    written to the other LDS buffer after them; one barrier per K-tile; 2 workgroups per CU (76 KB LDS each).
 //  * NHWC gathers are 16 B per lane, 128 B contiguous per 8 lanes; out-of-image taps load nothing.
 #include <cstdio>
+#include <cstdlib>
 #include "tg_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -163,11 +164,14 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
 
   const int frag = (lane & 31) * LDT + (lane >> 5) * 4;
 
+  // Register-staged double buffer: the global loads of tile it+1 are issued before the 64 MFMAs of tile it and written
+  // to the other LDS buffer after them (one barrier per K-tile).  (Measured alternative: writing tile it+1 FIRST and
+  // prefetching tile it+2 — one tile deeper — is 3-4 % slower here and 5 % faster in wgrad_f32_kernel, which uses it.)
+  int tap = 0, c0 = 0, buf = 0;
   gload(0, 0);
   sstore(0);
   __syncthreads();
 
-  int tap = 0, c0 = 0, buf = 0;
   for (int it = 0; it < nk; ++it) {
     const bool more = it + 1 < nk;
     if (more) {
@@ -227,7 +231,10 @@ struct WgradParams {
   float* slab;
   tg_igemm_desc d;
   int M, n_split, px_per_split, c_tiles, n_tiles;
+  uint32_t in_bytes, dout_bytes;
 };
+
+constexpr uint32_t WG_INVALID = 0x80000000u;   // byte offset beyond any (< 2 GiB) operand: the buffer range check yields zeros
 
 template <int CT, int NT, int WAVES_C, int WAVES_N, int WAVES_K>
 __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
@@ -237,9 +244,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
   constexpr int ASEG = CT / 4, BSEG = NT / 4;          // 16-B segments per pixel row
   constexpr int TILE = BK * (CT + NT);
   constexpr int RED = (WAVES_K > 1) ? (WAVES_K - 1) * 64 * 16 * MI * NI * WAVES_C * WAVES_N : 0;
-  constexpr int SM = (2 * TILE > RED ? 2 * TILE : RED) + 4 * BK;
+  constexpr int SM = (2 * TILE > RED ? 2 * TILE : RED) + 8 * BK;
   __shared__ __attribute__((aligned(16))) float smem[SM];
-  int* tbl = reinterpret_cast<int*>(smem + (2 * TILE > RED ? 2 * TILE : RED));   // [2][2][BK]: in_off, out_off
+  int* tbl = reinterpret_cast<int*>(smem + (2 * TILE > RED ? 2 * TILE : RED));   // [4 slots][2][BK]: in_off, out_off of pixel tile t in slot t & 3
 
   const tg_igemm_desc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -254,49 +261,54 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
   const int nk = (p_end > p_begin) ? (p_end - p_begin + BK - 1) / BK : 0;
   const int dy = d.dy[tap], dx = d.dx[tap];
 
-  auto fill_tbl = [&](int it) {          // threads < BK: offsets of pixel tile `it`
-    int px = p_begin + it * BK + tid;
-    int io = -1, oo = -1;
-    if (px < p_end) {
-      int hw = d.h_v * d.w_v;
-      int img = px / hw, rem = px - img * hw;
-      int vy = rem / d.w_v, vx = rem - vy * d.w_v;
-      int iy = vy * d.s_y + dy, ix = vx * d.s_x + dx;
+  // threads < BK walk their pixel (img, vy, vx) forward by BK per K-tile instead of dividing: the table fill sits on
+  // wave 0's path to the barrier, two integer divisions per tile cost ~10 % of the MFMA time.
+  int f_img = 0, f_vy = 0, f_vx = 0, f_px = p_begin + tid;
+  if (tid < BK) {
+    const int hw = d.h_v * d.w_v;
+    f_img = f_px / hw;
+    const int rem = f_px - f_img * hw;
+    f_vy = rem / d.w_v;
+    f_vx = rem - f_vy * d.w_v;
+  }
+  auto fill_tbl = [&](int it) {          // threads < BK: offsets of pixel tile `it`; MUST be called for it = 0, 1, 2, ... in order
+    uint32_t io = WG_INVALID, oo = WG_INVALID;
+    if (f_px < p_end) {
+      const int iy = f_vy * d.s_y + dy, ix = f_vx * d.s_x + dx;
       if ((unsigned)iy < (unsigned)d.h_in && (unsigned)ix < (unsigned)d.w_in)
-        io = ((img * d.h_in + iy) * d.w_in + ix) * d.ld_in;
-      oo = ((img * d.h_out + vy * d.os_y + d.oo_y) * d.w_out + vx * d.os_x + d.oo_x) * d.ld_out;
+        io = (uint32_t)(((f_img * d.h_in + iy) * d.w_in + ix) * d.ld_in) * 4u;
+      oo = (uint32_t)(((f_img * d.h_out + f_vy * d.os_y + d.oo_y) * d.w_out + f_vx * d.os_x + d.oo_x) * d.ld_out) * 4u;
     }
-    tbl[(it & 1) * 2 * BK + tid] = io;
-    tbl[(it & 1) * 2 * BK + BK + tid] = oo;
+    tbl[(it & 3) * 2 * BK + tid] = (int)io;
+    tbl[(it & 3) * 2 * BK + BK + tid] = (int)oo;
+    f_px += BK;
+    f_vx += BK;
+    while (f_vx >= d.w_v) { f_vx -= d.w_v; ++f_vy; }
+    while (f_vy >= d.h_v) { f_vy -= d.h_v; ++f_img; }
   };
 
   const int aseg = tid % ASEG, arow = tid / ASEG;      // rows advance by 256/ASEG per pass
   const int bseg = tid % BSEG, brow = tid / BSEG;
-  f32x4 ra[AR], rb[BR];
+  // both operands through buffer descriptors: masked pixels carry WG_INVALID and read zeros without a branch, so the
+  // loads stay in flight behind the MFMAs (see igemm_f32_kernel)
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_do = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dout), 0, p.dout_bytes, 0x00020000);
+  const uint32_t a_add = (uint32_t)(c0 + aseg * 4) * 4u, b_add = (uint32_t)(n0 + bseg * 4) * 4u;
+  u32x4 ra[AR], rb[BR];
   auto gload = [&](int it) {
-    const int* ti = tbl + (it & 1) * 2 * BK;
+    const int* ti = tbl + (it & 3) * 2 * BK;
 #pragma unroll
-    for (int j = 0; j < AR; ++j) {
-      int off = ti[arow + j * (256 / ASEG)];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (off >= 0) v = *reinterpret_cast<const f32x4*>(p.in + (off + c0 + aseg * 4));
-      ra[j] = v;
-    }
+    for (int j = 0; j < AR; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (uint32_t)ti[arow + j * (256 / ASEG)] + a_add, 0, 0);
 #pragma unroll
-    for (int j = 0; j < BR; ++j) {
-      int off = ti[BK + brow + j * (256 / BSEG)];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (off >= 0) v = *reinterpret_cast<const f32x4*>(p.dout + (off + n0 + bseg * 4));
-      rb[j] = v;
-    }
+    for (int j = 0; j < BR; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_do, (uint32_t)ti[BK + brow + j * (256 / BSEG)] + b_add, 0, 0);
   };
   auto sstore = [&](int buf) {
     float* a = smem + buf * TILE;
     float* bb = a + BK * CT;
 #pragma unroll
-    for (int j = 0; j < AR; ++j) *reinterpret_cast<f32x4*>(a + (arow + j * (256 / ASEG)) * CT + aseg * 4) = ra[j];
+    for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4*>(a + (arow + j * (256 / ASEG)) * CT + aseg * 4) = ra[j];
 #pragma unroll
-    for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(bb + (brow + j * (256 / BSEG)) * NT + bseg * 4) = rb[j];
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x4*>(bb + (brow + j * (256 / BSEG)) * NT + bseg * 4) = rb[j];
   };
 
   const int wk = wave % WAVES_K;
@@ -310,19 +322,23 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+  // same two-deep software pipeline as igemm_f32_kernel: registers hold tile it+1, LDS buffer `buf` tile it.  The offset
+  // table has 4 slots: iteration it reads slot (it+2)&3 for its loads and fills slot (it+3)&3 (last read two iterations
+  // ago) before the barrier that publishes it.
+  const int half = lane >> 5, col = lane & 31;
+  int buf = 0;
   if (nk > 0) {
-    if (tid < BK) { fill_tbl(0); if (nk > 1) fill_tbl(1); }
+    if (tid < BK) { fill_tbl(0); if (nk > 1) fill_tbl(1); if (nk > 2) fill_tbl(2); }
     __syncthreads();
     gload(0);
     sstore(0);
+    if (nk > 1) gload(1);
     __syncthreads();
   }
-  const int half = lane >> 5, col = lane & 31;
-  int buf = 0;
   for (int it = 0; it < nk; ++it) {
-    const bool more = it + 1 < nk;
-    if (more) gload(it + 1);
-    if (tid < BK && it + 2 < nk) fill_tbl(it + 2);   // table slot (it&1) was last read for tile `it`
+    if (it + 1 < nk) sstore(buf ^ 1);
+    if (it + 2 < nk) gload(it + 2);
+    if (tid < BK && it + 3 < nk) fill_tbl(it + 3);
     const float* A = smem + buf * TILE + (16 * half) * CT + wc0 + col;
     const float* B = smem + buf * TILE + BK * CT + (16 * half) * NT + wn0 + col;
 #pragma unroll
@@ -338,7 +354,6 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi][ni], 0, 0, 0);
     }
-    if (more) sstore(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
@@ -444,11 +459,25 @@ extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const 
   tg::ProfScope prof(tg::PC_IGEMM, flops, bytes, s, desc);
   // tile choice: the largest tile that still gives >= ~1.5 workgroups per CU (2 are resident); small problems (generator,
   // discriminator tail, ZCA) fall back to 64-row / 64-column tiles for parallelism.
-  int bn = d->c_out % 128 == 0 ? 128 : (d->c_out % 64 == 0 ? 64 : 32);
-  int bm = 128;
-  auto blocks = [&](int m, int n) { return (int64_t)n_desc * ((p.M + m - 1) / m) * (d->c_out / n); };
-  if (blocks(bm, bn) < 384 && bn == 128) bn = 64;
-  if (blocks(bm, bn) < 384 && bn >= 64) bm = 64;
+  // tile choice by a wave-quantisation cost model: time ~ ceil(blocks / resident slots) * tile area / efficiency.
+  // 520 tiles of 128x128 on 512 slots take two rounds; the same problem in 64x64 tiles takes 2080/1024 -> 3 quarter-size
+  // rounds.  Small problems (generator, discriminator tail, ZCA) end up on 64-row / 64-column tiles for parallelism.
+  struct Cand { int bm, bn, slots; double eff; };
+  static const Cand cands[] = {{128, 128, 512, 1.00}, {128, 64, 512, 0.93}, {64, 128, 512, 0.90}, {64, 64, 1024, 0.80}, {128, 32, 768, 0.70}};
+  int bm = 128, bn = 32;
+  double best = 1e300;
+  const char* force = getenv("TG_IGEMM_TILE");     // "bm,bn" — tuning aid
+  int fbm = 0, fbn = 0;
+  if (force) sscanf(force, "%d,%d", &fbm, &fbn);
+  for (const Cand& c : cands) {
+    if (d->c_out % c.bn) continue;
+    if (force && (c.bm != fbm || c.bn != fbn)) continue;
+    const int64_t blocks = (int64_t)n_desc * ((p.M + c.bm - 1) / c.bm) * (d->c_out / c.bn);
+    const double rounds = (double)((blocks + c.slots - 1) / c.slots);
+    // the last round is only as long as its fullest CU: model a partially filled final round linearly above 1 tile
+    const double t = rounds * c.bm * c.bn / c.eff;
+    if (t < best) { best = t; bm = c.bm; bn = c.bn; }
+  }
   if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2>(p, s);
   else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2>(p, s);
   else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2>(p, s);
@@ -476,8 +505,11 @@ extern "C" int tg_wgrad_f32(const tg_igemm_desc* d, const float* in, const float
   TG_REQUIRE(in && dout && slab, "wgrad: null buffer");
   TG_REQUIRE(n_split >= 1, "wgrad: n_split=%d", n_split);
   TG_REQUIRE(d->c_out <= d->ld_out, "wgrad: c_out=%d exceeds ld_out=%d", d->c_out, d->ld_out);
-  WgradParams p{in, dout, slab, *d, 0, n_split, 0, 0, 0};
+  WgradParams p{in, dout, slab, *d, 0, n_split, 0, 0, 0, 0, 0};
   p.M = d->n_img * d->h_v * d->w_v;
+  const int64_t ib = (int64_t)d->n_img * d->h_in * d->w_in * d->ld_in * 4, ob = (int64_t)d->n_img * d->h_out * d->w_out * d->ld_out * 4;
+  TG_REQUIRE(ib < 0x7FFFFFF0LL && ob < 0x7FFFFFF0LL, "wgrad: operand exceeds the 2 GiB buffer-descriptor range");
+  p.in_bytes = (uint32_t)ib; p.dout_bytes = (uint32_t)ob;
   p.px_per_split = (((p.M + n_split - 1) / n_split) + BK - 1) / BK * BK;
   const double flops = 2.0 * p.M * d->c_out * d->n_taps * d->ld_in;
   const double bytes = 4.0 * ((double)p.M * d->ld_in + (double)p.M * d->c_out + (double)n_split * d->c_out * d->n_taps * d->ld_in);

@@ -92,20 +92,32 @@ __global__ void __launch_bounds__(256) colstats_stage1(const float* __restrict__
   }
 }
 
-__global__ void colstats_stage2(const double* __restrict__ part, SegTable st, int c_pad, int c, float* __restrict__ s1, float* __restrict__ s2) {
+// stage 2: 32 columns x 8 chunk-lanes per block; lane l sums chunks l, l+8, ... (fixed order => reproducible), then an
+// LDS tree.  (A single thread per column walking all ~1000 chunks is a 30 us dependent-load chain.)
+__global__ void __launch_bounds__(256) colstats_stage2(const double* __restrict__ part, SegTable st, int c_pad, int c, float* __restrict__ s1,
+                                                        float* __restrict__ s2) {
   const int seg = blockIdx.y;
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= c) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + tx;
   int ch0 = 0;
   for (int s = 0; s < seg; ++s) ch0 += (st.rows[s] + RCH - 1) / RCH;
   const int n = (st.rows[seg] + RCH - 1) / RCH;
   double a1 = 0., a2 = 0.;
-  for (int k = 0; k < n; ++k) {
-    a1 += part[((int64_t)(ch0 + k) * 2) * c_pad + col];
-    a2 += part[((int64_t)(ch0 + k) * 2 + 1) * c_pad + col];
+  if (col < c) {
+    for (int k = ty; k < n; k += 8) {
+      a1 += part[((int64_t)(ch0 + k) * 2) * c_pad + col];
+      a2 += part[((int64_t)(ch0 + k) * 2 + 1) * c_pad + col];
+    }
   }
-  s1[seg * c + col] = (float)a1;
-  if (s2) s2[seg * c + col] = (float)a2;
+  __shared__ double red[2][8][32];
+  red[0][ty][tx] = a1;
+  red[1][ty][tx] = a2;
+  __syncthreads();
+  if (ty == 0 && col < c) {
+    for (int k = 1; k < 8; ++k) { a1 += red[0][k][tx]; a2 += red[1][k][tx]; }
+    s1[seg * c + col] = (float)a1;
+    if (s2) s2[seg * c + col] = (float)a2;
+  }
 }
 
 // y[r][c] = act(x[r][c]*scale[c] + shift[seg(r)][c]) for c < C; zero for C <= c < c_zero_to.
@@ -308,7 +320,7 @@ int tg_colstats_f32(int mode, const float* a, int ld_a, const float* b, int ld_b
     default: tg::set_error("colstats: bad mode %d", mode); return TG_ERR_INVALID;
   }
   TG_CHECK_LAUNCH("colstats_stage1");
-  hipLaunchKernelGGL(colstats_stage2, dim3((c + 127) / 128, nseg), dim3(128), 0, s, wsd, st, c_pad, c, s1, s2);
+  hipLaunchKernelGGL(colstats_stage2, dim3((c + 31) / 32, nseg), dim3(256), 0, s, wsd, st, c_pad, c, s1, s2);
   TG_CHECK_LAUNCH("colstats_stage2");
   return TG_OK;
 }

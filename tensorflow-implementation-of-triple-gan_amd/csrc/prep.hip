@@ -8,37 +8,57 @@
 namespace {
 
 // scale[c] = g[c] * rsqrt(max(sum_r V[r][c]^2, 1e-12))        (tf.nn.l2_normalize, Model/nn.py:502)
-__global__ void __launch_bounds__(256) wn_scale(const float* __restrict__ v, const float* __restrict__ g, int r, int c, float* __restrict__ scale) {
-  const int col = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
-  float acc = 0.f;
-  if (col < c)
-    for (int i = ry; i < r; i += 8) { const float t = v[(int64_t)i * c + col]; acc += t * t; }
-  __shared__ float red[8][32];
-  red[ry][threadIdx.x & 31] = acc;
+// 32 columns x 32 row-lanes per 1024-thread block: the row loop is a dependent-load chain, so it is kept short
+// (rows/32 steps, 4 loads in flight per lane) — a filter has only c/32 = 4..16 such column groups.
+__global__ void __launch_bounds__(1024) wn_scale(const float* __restrict__ v, const float* __restrict__ g, int r, int c, float* __restrict__ scale) {
+  const int tx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + tx;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < c) {
+    int i = ry;
+    for (; i + 96 < r; i += 128) {
+      const float t0 = v[(int64_t)i * c + col], t1 = v[(int64_t)(i + 32) * c + col], t2 = v[(int64_t)(i + 64) * c + col],
+                  t3 = v[(int64_t)(i + 96) * c + col];
+      a0 += t0 * t0; a1 += t1 * t1; a2 += t2 * t2; a3 += t3 * t3;
+    }
+    for (; i < r; i += 32) { const float t = v[(int64_t)i * c + col]; a0 += t * t; }
+  }
+  float acc = (a0 + a1) + (a2 + a3);
+  __shared__ float red[32][33];
+  red[ry][tx] = acc;
   __syncthreads();
   if (ry == 0 && col < c) {
-    for (int k = 1; k < 8; ++k) acc += red[k][threadIdx.x & 31];
+    for (int k = 1; k < 32; ++k) acc += red[k][tx];
     scale[col] = g[col] * rsqrtf(fmaxf(acc, 1e-12f));
   }
 }
 
 // dg[c] = <dW[:,c], V[:,c]> / ||V[:,c]|| ;  coef[c] = {g/||V||, <dW,V>/||V||^2}
-__global__ void __launch_bounds__(256) wn_bwd_cols(const float* __restrict__ dw, const float* __restrict__ v, const float* __restrict__ g, int r, int c,
-                                                   float* __restrict__ dg, float* __restrict__ coef) {
-  const int col = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
-  float dot = 0.f, ss = 0.f;
-  if (col < c)
-    for (int i = ry; i < r; i += 8) {
-      const float t = v[(int64_t)i * c + col];
-      dot += dw[(int64_t)i * c + col] * t;
-      ss += t * t;
+__global__ void __launch_bounds__(1024) wn_bwd_cols(const float* __restrict__ dw, const float* __restrict__ v, const float* __restrict__ g, int r, int c,
+                                                    float* __restrict__ dg, float* __restrict__ coef) {
+  const int tx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + tx;
+  float d0 = 0.f, d1 = 0.f, s0 = 0.f, s1 = 0.f;
+  if (col < c) {
+    int i = ry;
+    for (; i + 32 < r; i += 64) {
+      const float t0 = v[(int64_t)i * c + col], t1 = v[(int64_t)(i + 32) * c + col];
+      const float w0 = dw[(int64_t)i * c + col], w1 = dw[(int64_t)(i + 32) * c + col];
+      d0 += w0 * t0; d1 += w1 * t1; s0 += t0 * t0; s1 += t1 * t1;
     }
-  __shared__ float red[2][8][32];
-  red[0][ry][threadIdx.x & 31] = dot;
-  red[1][ry][threadIdx.x & 31] = ss;
+    for (; i < r; i += 32) {
+      const float t = v[(int64_t)i * c + col];
+      d0 += dw[(int64_t)i * c + col] * t;
+      s0 += t * t;
+    }
+  }
+  float dot = d0 + d1, ss = s0 + s1;
+  __shared__ float red[2][32][33];
+  red[0][ry][tx] = dot;
+  red[1][ry][tx] = ss;
   __syncthreads();
   if (ry == 0 && col < c) {
-    for (int k = 1; k < 8; ++k) { dot += red[0][k][threadIdx.x & 31]; ss += red[1][k][threadIdx.x & 31]; }
+    for (int k = 1; k < 32; ++k) { dot += red[0][k][tx]; ss += red[1][k][tx]; }
     const float nrm = sqrtf(ss);
     dg[col] = dot / nrm;
     coef[col] = g[col] / nrm;
@@ -110,7 +130,7 @@ int tg_wn_scale_f32(const float* v, const float* g, int rows, int c, float* scal
   TG_REQUIRE(v && g && scale && rows > 0 && c > 0, "wn_scale: bad args");
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * rows * c, s);
-  hipLaunchKernelGGL(wn_scale, dim3((c + 31) / 32), dim3(256), 0, s, v, g, rows, c, scale);
+  hipLaunchKernelGGL(wn_scale, dim3((c + 31) / 32), dim3(1024), 0, s, v, g, rows, c, scale);
   TG_CHECK_LAUNCH("wn_scale");
   return TG_OK;
 }
@@ -140,7 +160,7 @@ int tg_wn_bwd_f32(const float* dw, const float* v, const float* g, int rows, int
   TG_REQUIRE(dw && v && g && dv && dg && coef, "wn_bwd: null buffer");
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * rows * c * 5, s);
-  hipLaunchKernelGGL(wn_bwd_cols, dim3((c + 31) / 32), dim3(256), 0, s, dw, v, g, rows, c, dg, coef);
+  hipLaunchKernelGGL(wn_bwd_cols, dim3((c + 31) / 32), dim3(1024), 0, s, dw, v, g, rows, c, dg, coef);
   TG_CHECK_LAUNCH("wn_bwd_cols");
   hipLaunchKernelGGL(wn_bwd_apply, dim3(ew_grid((int64_t)rows * c)), dim3(256), 0, s, dw, v, coef, (int64_t)rows * c, c, dv);
   TG_CHECK_LAUNCH("wn_bwd_apply");

@@ -5,7 +5,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libtg_hip.so")
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", os.environ.get("TG_LIB", "libtg_hip.so"))
 
 TG_MAX_TAPS = 25
 ACT = {None: 0, 'none': 0, 'lrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4, 'softplus': 5}

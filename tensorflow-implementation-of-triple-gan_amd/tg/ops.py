@@ -41,10 +41,12 @@ def colstats(mode, a_t, ld_a, b_t, ld_b, rows, c, seg_rows, act=None, alpha=0.2,
 
 
 def wgrad_splits(desc, m):
+    """pixel splits of tg_wgrad_f32: fill ONE round of the 512 resident workgroups (256 CUs x 2) as fully as possible —
+    576 blocks take two rounds and run at 56 % — with at least 128 pixels (4 K-tiles) per split."""
     ct = 128 if desc.ld_in % 128 == 0 else (64 if desc.ld_in % 64 == 0 else 32)
     nt = 128 if desc.c_out % 128 == 0 else (64 if desc.c_out % 64 == 0 else 32)
     tiles = desc.n_taps * (desc.ld_in // ct) * (desc.c_out // nt)
-    return max(1, min(-(-768 // tiles), m // 512))
+    return max(1, min(512 // tiles, m // 128))
 
 
 def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst):

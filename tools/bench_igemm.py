@@ -35,10 +35,12 @@ for name, hw, ci, co, k, pad in LAYERS:
     ms = timeit(lambda: lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st))
     fl = 2.0 * N * ho * ho * co * k * k * ci
     print("fwd   %-26s %8.3f ms  %7.1f TFLOP/s" % (name, ms, fl / ms / 1e9))
+    if os.environ.get('FWD_ONLY'):
+        continue
     dy = torch.randn(N, ho, ho, co, device='cuda')
     dw = geom.conv_wgrad(N, hw, hw, ci, co, k, 1, pad)
     tiles = k * k * (ci // 128) * (co // 128)
-    nsplit = max(1, min(64, 768 // tiles))
+    nsplit = max(1, min(512 // tiles, (N * ho * ho) // 512))
     slab = torch.empty(nsplit, k * k, ci, co, device='cuda')
     ms = timeit(lambda: lib.call("tg_wgrad_f32", dw, lib.ptr(x), lib.ptr(dy), lib.ptr(slab), nsplit, st))
     print("wgrad %-26s %8.3f ms  %7.1f TFLOP/s  (split %d)" % (name, ms, fl / ms / 1e9, nsplit))
