@@ -1,0 +1,87 @@
+"""CPU checks of the drop-in boundary: libtg_hip.so loads without a GPU and exports every symbol that
+include/tg_kernels.h declares; error reporting works; the product path refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "tg_kernels.h")
+
+
+def test_header_is_plain_c():
+    subprocess.check_call(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", HEADER])
+
+
+def test_library_exports_every_declared_symbol():
+    from tg import lib
+    sigs = lib.parse_header()
+    text = open(HEADER).read()
+    declared = set(re.findall(r"\b(tg_\w+)\s*\(", re.sub(r"/\*.*?\*/", "", text, flags=re.S)))
+    declared -= {"tg_status", "tg_igemm_desc"}
+    assert declared == set(sigs), declared ^ set(sigs)
+    assert len(sigs) >= 50
+    handle = lib.load()
+    for name in sigs:
+        assert hasattr(handle, name), name
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (tg_\w+)", exported))
+    assert exported == set(sigs), exported ^ set(sigs)       # nothing undeclared is exported either
+
+
+def test_no_torch_types_in_signatures():
+    text = open(HEADER).read()
+    assert "torch" not in text and "at::" not in text and "#include <hip" not in text
+
+
+def test_version_and_error_string_without_gpu(has_gpu):
+    from tg import lib
+    assert lib.call("tg_version") >= 100
+    n = lib.call("tg_device_count")
+    if not has_gpu:
+        assert n < 0 and b"hipGetDeviceCount" in lib.load().tg_last_error_string()
+    else:
+        assert n >= 1
+
+
+def test_desc_struct_matches_header_layout():
+    """sizeof / offsets of the ctypes mirror against the C compiler's view of tg_igemm_desc."""
+    from tg import lib
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu\\n", sizeof(tg_igemm_desc), ' \
+          'offsetof(tg_igemm_desc, dy), offsetof(tg_igemm_desc, tapw), offsetof(tg_igemm_desc, w_sn), offsetof(tg_igemm_desc, alpha));return 0;}' % HEADER
+    exe = "/tmp/tg_desc_layout"
+    subprocess.run(["gcc", "-x", "c", "-", "-o", exe], input=src.encode(), check=True)
+    got = [int(v) for v in subprocess.check_output([exe]).split()]
+    D = lib.IgemmDesc
+    assert got == [C.sizeof(D), D.dy.offset, D.tapw.offset, D.w_sn.offset, D.alpha.offset]
+
+
+def test_product_path_fails_loudly_without_gpu(has_gpu):
+    if has_gpu:
+        pytest.skip("GPU present")
+    from tg import lib, runtime
+    with pytest.raises(lib.TgError, match="no MI355X"):
+        runtime.Context()
+    with pytest.raises(lib.TgError, match="no tg Context"):
+        runtime.set_context(None)
+        runtime.ctx()
+
+
+def test_missing_extension_is_an_error(monkeypatch):
+    from tg import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libtg_hip.so")
+    with pytest.raises(lib.TgError, match="HIP extension missing"):
+        lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under the package may import, link or execute it."""
+    pkg = os.path.join(ROOT, "tensorflow-implementation-of-triple-gan_amd")
+    pat = re.compile(r"^\s*(from|import)\s+oracle|oracle[/.](tf_ops|nets_|step_)|['\"]oracle['\"]", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), os.path.join(dirpath, f)
