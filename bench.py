@@ -10,10 +10,12 @@ already resident in HBM, random-init weights, synthetic orthogonal ZCA.  images/
 replicas (weak scaling: every replica runs the single-GPU batch; gradients are sum-all-reduced over RCCL).
 
 The JSON line also carries
-  roofline     — the MFMA implicit-GEMM kernel class (conv fwd / dgrad / deconv / dense): algorithmic FLOPs of its launches
-                 in one iteration / their summed HIP-event durations, measured in an instrumented eager pass on the
-                 launch stream right after the timed region (the timed region itself replays hipGraphs, whose inner
-                 kernels cannot be bracketed by events); peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).
+  roofline     — the classifier's 3x3 convolution path (87 % of the step's FLOPs; the north-star kernel path): algorithmic
+                 FLOPs of its igemm (forward + input-gradient) and wgrad launches in one iteration / their summed
+                 HIP-event durations, measured in an instrumented eager pass on the launch stream right after the timed
+                 region (the timed region replays hipGraphs, whose inner kernels cannot be bracketed by events);
+                 peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).  The figure over ALL igemm / wgrad launches
+                 (generator, discriminator, dense, ZCA included) is reported next to it.
   cpu_baseline — the NumPy oracle (oracle/step_cifar10.py, a port: TF1 is not installable) timed on this host's cores
                  for one iteration of the same workload (rank 0, N = 1 only).
 """
@@ -179,17 +181,49 @@ def main():
         name = lib.load().tg_prof_class_name(cls).decode()
         classes[name] = dict(ms_per_iter=ms.value / args.prof_iters, launches_per_iter=n.value / args.prof_iters,
                              executed_gflop_per_iter=f.value / args.prof_iters / 1e9, gbytes_per_iter=b.value / args.prof_iters / 1e9)
-    if os.environ.get('TG_PROF_DUMP'):
-        lib.call('tg_prof_dump', os.environ['TG_PROF_DUMP'].encode())
+    dump = os.environ.get('TG_PROF_DUMP') or os.path.join('/tmp', 'tg_prof_%d.csv' % os.getpid())
+    lib.call('tg_prof_dump', dump.encode())
     lib.call('tg_prof_reset')
+    # the north-star kernel path: the seven 3x3 convolutions of the classifier (forward, input gradient, filter
+    # gradient).  Their launches are recognised by geometry: 9 taps, classifier channel widths, stride 1.
+    import csv
+    import re
+    conv_ms = {'igemm_f32': 0.0, 'wgrad_f32': 0.0}
+    conv_n = {'igemm_f32': 0, 'wgrad_f32': 0}
+    for row in csv.DictReader(open(dump)):
+        m = re.match(r"M=(?:\d+x)?(\d+) N=(\d+) K=(\d+)x(\d+) in=(\d+)x\d+ s=(\d+)", row['desc'] or '')
+        if not m or row['class'] not in conv_ms:
+            continue
+        mm, n, taps, ld, hin, st = (int(v) for v in m.groups())
+        if taps == 9 and st == 1 and ld in (32, 128, 256, 512) and n in (32, 128, 256, 512) and hin in (32, 16, 8, 6) and max(ld, n) >= 128:
+            conv_ms[row['class']] += float(row['ms']) / args.prof_iters
+            conv_n[row['class']] += 1
+    if not os.environ.get('TG_PROF_DUMP'):
+        os.remove(dump)
+    s_ = SIZES
+    n_c = s_['L_C'] + 2 * s_['U_C'] + s_['B_G']
+    n_cd = s_['U_C'] + s_['U_D']
+    mf = lambda h, ci, co: 2.0 * h * h * 9 * ci * co
+    c3 = [mf(32, 3, 128), mf(32, 128, 128), mf(32, 128, 128), mf(16, 128, 256), mf(16, 256, 256), mf(16, 256, 256), mf(6, 256, 512)]
+    conv_fl_ig = (n_c + n_cd) * sum(c3) + n_c * sum(c3[1:])          # forward (C- and D-update) + input gradients
+    conv_fl_wg = n_c * sum(c3)
+    conv_tf_ig = conv_fl_ig / (conv_ms['igemm_f32'] * 1e-3) / 1e12
+    conv_tf_wg = conv_fl_wg / (conv_ms['wgrad_f32'] * 1e-3) / 1e12
+    conv_tf = (conv_fl_ig + conv_fl_wg) / ((conv_ms['igemm_f32'] + conv_ms['wgrad_f32']) * 1e-3) / 1e12
     ig = classes['igemm_f32']
     achieved = fl['igemm'] / (ig['ms_per_iter'] * 1e-3) / 1e12
-    roofline = dict(bound="mfma", kernel="igemm_f32_kernel (conv fwd/dgrad, deconv, dense)", achieved=round(achieved, 2),
-                    peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
-                    launches_per_step=ig['launches_per_iter'], avg_launch_ms=round(ig['ms_per_iter'] / max(ig['launches_per_iter'], 1), 5),
-                    algorithmic_gflop_per_step=round(fl['igemm'] / 1e9, 1),
-                    wgrad_f32=dict(achieved=round(fl['wgrad'] / (classes['wgrad_f32']['ms_per_iter'] * 1e-3) / 1e12, 2),
-                                   algorithmic_gflop_per_step=round(fl['wgrad'] / 1e9, 1)),
+    n_conv_launches = (conv_n['igemm_f32'] + conv_n['wgrad_f32']) / args.prof_iters
+    roofline = dict(bound="mfma", kernel="classifier 3x3 conv path: igemm_f32_kernel (fwd + input grad) + wgrad_f32_kernel",
+                    achieved=round(conv_tf, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(conv_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                    traffic=None, launches_per_step=n_conv_launches,
+                    avg_launch_ms=round((conv_ms['igemm_f32'] + conv_ms['wgrad_f32']) / max(n_conv_launches, 1), 5),
+                    algorithmic_gflop_per_step=round((conv_fl_ig + conv_fl_wg) / 1e9, 1),
+                    conv3x3_igemm=dict(achieved=round(conv_tf_ig, 2), ms_per_step=round(conv_ms['igemm_f32'], 3)),
+                    conv3x3_wgrad=dict(achieved=round(conv_tf_wg, 2), ms_per_step=round(conv_ms['wgrad_f32'], 3)),
+                    all_igemm_launches=dict(achieved=round(achieved, 2), frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                                            launches_per_step=ig['launches_per_iter'], algorithmic_gflop_per_step=round(fl['igemm'] / 1e9, 1)),
+                    all_wgrad_launches=dict(achieved=round(fl['wgrad'] / (classes['wgrad_f32']['ms_per_iter'] * 1e-3) / 1e12, 2),
+                                            algorithmic_gflop_per_step=round(fl['wgrad'] / 1e9, 1)),
                     class_ms_per_step={k: round(v['ms_per_iter'], 3) for k, v in classes.items()})
 
     if rank == 0:

