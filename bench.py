@@ -195,7 +195,8 @@ def main():
         if not m or row['class'] not in conv_ms:
             continue
         mm, n, taps, ld, hin, st = (int(v) for v in m.groups())
-        if taps == 9 and st == 1 and ld in (32, 128, 256, 512) and n in (32, 128, 256, 512) and hin in (32, 16, 8, 6) and max(ld, n) >= 128:
+        conv1_1 = taps == 1 and ld == 32 and n == 128 and hin == 32        # first conv runs as a 1x1 product on 3x3 patches
+        if conv1_1 or (taps == 9 and st == 1 and ld in (128, 256, 512) and n in (128, 256, 512) and hin in (32, 16, 8, 6)):
             conv_ms[row['class']] += float(row['ms']) / args.prof_iters
             conv_n[row['class']] += 1
     if not os.environ.get('TG_PROF_DUMP'):

@@ -157,6 +157,9 @@ int tg_bn_bwd_apply_f32(const float* dy, int ld_dy, const float* x, int ld_x, fl
 /* out[r][:c] = x[r][:c] + add[r][:c] (add may be NULL), zero up to ld_out.  Gaussian input noise of the classifier
  * (Model/modle_base.py:193-202 via Good_GAN_cifar10.py:104) + channel padding. */
 int tg_pad_add_f32(const float* x, int ld_x, int c, const float* add, int ld_add, float* out, int ld_out, int rows, void* stream);
+/* 3x3 SAME stride-1 patches of (x + add), x dense [n,h,w,c]: out[(n,y,x)][t*c+k], zero outside the image and up to ld_out.
+ * Lets the classifier's first convolution (Cin = 3, Model/Good_GAN_cifar10.py:106) run as a K = 27 -> 32 dense product. */
+int tg_im2col3x3_add_f32(const float* x, const float* add, int n, int h, int w, int c, float* out, int ld_out, void* stream);
 /* out[n,p,:] = [x[n,p,:c]*mask*mscale, y[n,:ncls], 0...]: dropout (modle_base.py:190-191) + _conv_cond_concat
  * (modle_base.py:239-244).  mask may be NULL. */
 int tg_cond_concat_f32(const float* x, int ld_x, int c, const float* mask, int ld_mask, float mscale, const float* y, int ncls, float* out,

@@ -150,9 +150,13 @@ class Good_GAN_cifar10(model_base.NN_Base):
                   use_mean_only_batch_normalization=True, deterministic=not is_training, nonlinearity=self.leakyReLu,
                   segments=segments)
         with cx.variable_scope('classifier'):
-            x = self._add_noise(inp, stddev=0.15)
+            # x = self._add_noise(x, stddev=0.15) followed by conv1_1 (:104-110): with 3 input channels the 3x3 window is
+            # gathered once (x + noise -> [N,32,32,27]) and conv1_1 runs as a 1x1 product on it with the same variable V
+            # ([3,3,3,128] and [1,1,27,128] are the same bytes)
+            noise = cx.rng.normal(cx, 'noise', inp.rows * inp.c, 0.15)
+            x = ops.im2col3x3_add(inp, noise)
             for name, cout, pad in C_CONVS:
-                x = nn.conv2d_WN(x, num_filters=cout, name=name, pad=pad, **kw)
+                x = nn.conv2d_WN(x, num_filters=cout, name=name, pad=pad, filter_size=[1, 1] if name == 'conv1_1' else [3, 3], **kw)
                 if name in ('conv1_3', 'conv2_3'):                                   # max_pool_k + dropout_k (:123-124,142-143)
                     mask = None
                     if is_training:

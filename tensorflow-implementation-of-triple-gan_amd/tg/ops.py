@@ -254,6 +254,16 @@ def pad_add(x, add_t, ld_out):
     return out
 
 
+def im2col3x3_add(x, add_t):
+    """3x3 SAME patches of (x + noise) as a [n,h,w,9*c] activation (channel stride padded to 32): the classifier's
+    first conv then runs as a 1x1 product over K = 27 instead of K = 9*32 (no gradient is needed upstream)."""
+    cx = ctx()
+    assert x.ld == x.c
+    out = cx.new_act(x.n, x.h, x.w, 9 * x.c, pad32(9 * x.c))
+    _call('tg_im2col3x3_add_f32', x.ptr, _p(add_t), x.n, x.h, x.w, x.c, out.ptr, out.ld, cx.stream)
+    return out
+
+
 def maxpool2_dropout(y, mask_t, mscale):
     """tf.nn.max_pool 2x2 + tf.layers.dropout (Model/Good_GAN_cifar10.py:123-124)."""
     cx = ctx()
