@@ -105,10 +105,17 @@ int tg_wn_scale_f32(const float* v, const float* g, int rows, int c, float* scal
 /* Re-layout of a filter src[t][a][b] (b contiguous; optional per-b `scale`) with zero channel padding:
  *   dst_same[t][a][b]            -> [t][a_pad][b_pad]         (may be NULL)
  *   dst_tr[b*tr_sb + t*tr_st + a] for b < b_pad, a < a_pad   (may be NULL)
+ * `scale` multiplies per b, `scale_a` per a (either may be NULL).
  * HWIO conv filter -> OTI for tg_igemm_f32 forward (tr_sb = t*a_pad, tr_st = a_pad) and padded HWIO for the
  * input-gradient; [kh,kw,Cout,Cin] transposed-conv filter -> padded copy and per-tap transpose. */
-int tg_filter_prep_f32(const float* src, const float* scale, int t, int a, int b, int a_pad, int b_pad, float* dst_same, float* dst_tr,
-                       int64_t tr_sb, int64_t tr_st, void* stream);
+int tg_filter_prep_f32(const float* src, const float* scale, const float* scale_a, int t, int a, int b, int a_pad, int b_pad, float* dst_same,
+                       float* dst_tr, int64_t tr_sb, int64_t tr_st, void* stream);
+
+/* weight norm of a transposed-conv filter V[t][a][b] = [kh*kw][Cout][Cin] over axes (0,1,3) (NN_Base._WN_deconv2d,
+ * Model/modle_base.py:148): scale_a[a] = g[a]*rsqrt(max(sum_{t,b} V^2, 1e-12)) (feed it to tg_filter_prep_f32), and the
+ * gradients of W = g V/||V|| given dW in the same layout. */
+int tg_wn_scale_tab_f32(const float* v, const float* g, int t, int a, int b, float* scale_a, void* stream);
+int tg_wn_bwd_tab_f32(const float* dw, const float* v, const float* g, int t, int a, int b, float* dv, float* dg, void* stream);
 
 /* dst[t][c][n] = sum_s slab[s][t][c][n] (c < c_dim, n < n_dim): finishes tg_wgrad_f32, drops channel padding. */
 int tg_slab_reduce_f32(const float* slab, int n_split, int t, int c_pad, int n_pad, int c_dim, int n_dim, float* dst, void* stream);
@@ -145,6 +152,9 @@ int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nse
  * moving statistics updated in place when non-NULL (bessel = use the unbiased variance, the fused 4-D kernel). */
 int tg_bn_finalize_f32(const float* s1, const float* s2, int rows, int c, const float* gamma, const float* beta, float eps, float* scale,
                        float* shift, float* mean_inv, float* moving_mean, float* moving_var, float decay, int bessel, void* stream);
+/* inference-mode batch norm (is_training=False): scale = gamma*rsqrt(moving_var+eps), shift = beta - moving_mean*scale. */
+int tg_bn_eval_finalize_f32(int c, const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps,
+                            float* scale, float* shift, void* stream);
 /* from s_dy = sum dy, s_dyx = sum dy*x: dgamma, dbeta and abc = [A | B | C] with dx = A*dy + B*x + C. */
 int tg_bn_bwd_finalize_f32(const float* s_dy, const float* s_dyx, int rows, int c, const float* gamma, const float* mean_inv, float* abc,
                            float* dgamma, float* dbeta, void* stream);
@@ -181,6 +191,8 @@ int tg_gavgpool_bwd_f32(const float* dfeat, int ld_d, const float* yact, int ld_
                         float alpha, void* stream);
 int tg_copy2d_f32(const float* src, int64_t ld_s, float* dst, int64_t ld_d, int64_t rows, int64_t c, void* stream);
 int tg_fill_f32(float* dst, float value, int64_t n, void* stream);
+/* dst = a + b (dst may alias a or b): sums the per-application gradient buffers of a network applied several times. */
+int tg_add_f32(float* dst, const float* a, const float* b, int64_t n, void* stream);
 /* tf.one_hot(tf.argmax(logits,1)) (Good_GAN_cifar10.py:232,237,259,270); out [n][k]. */
 int tg_argmax_onehot_f32(const float* logits, int ld, int n, int k, float* out, void* stream);
 

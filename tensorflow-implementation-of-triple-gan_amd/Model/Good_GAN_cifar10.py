@@ -171,6 +171,11 @@ class Good_GAN_cifar10(model_base.NN_Base):
         return logits, intermediate_layer
 
     # ------------------------------------------------------------------ whole graph (evaluation / tests)
+    CONSISTENCY = True        # forward_pass returns C_unl_logits_rep and _loss_GAN adds lambda_2 * MSE (:232-235, train_base.py:118)
+
+    def as_image(self, a):
+        return a
+
     def zca(self):
         if self._zca is None:
             self._zca = cifar10_ZCA(self.config)

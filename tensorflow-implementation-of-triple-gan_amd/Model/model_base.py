@@ -42,6 +42,19 @@ class NN_Base(object):
         raise NotImplementedError("standalone tanh is always fused: pass activation=self._tanh")
     _tanh.tg_act = ('tanh', 0.0)
 
+    def _leaky_relu(self, x, alpha=0.2):
+        """tf.nn.leaky_relu (default alpha 0.2; modle_base.py:181-182) — fused: pass activation=self._leaky_relu."""
+        raise NotImplementedError("standalone leaky_relu is always fused: pass activation=self._leaky_relu")
+    _leaky_relu.tg_act = ('lrelu', 0.2)
+
+    def _softplus(self, x):
+        raise NotImplementedError("standalone softplus is always fused: pass activation=self._softplus")
+    _softplus.tg_act = ('softplus', 0.0)
+
+    def _sigmoid(self, x):
+        raise NotImplementedError("standalone sigmoid is always fused: pass activation=self._sigmoid")
+    _sigmoid.tg_act = ('sigmoid', 0.0)
+
     # ---- layers -----------------------------------------------------------------------------------
     def _linear_fc(self, input_, output_size, scope=None, bias_start=0.0, use_bias=True, kernel_initializer=None,
                    activation=None, narrow=False):
@@ -80,34 +93,72 @@ class NN_Base(object):
 
     def _batch_norm_contrib(self, x, name, train=False):
         """tf.contrib.layers.batch_norm(decay, eps, scale=True, updates_collections=None) (modle_base.py:229-237).
-        Only the training branch is ever executed by the reference's models."""
-        if not train:
-            raise NotImplementedError("inference-mode batch norm is never executed by the reference's generator")
+        train=True: batch statistics, moving statistics updated in place; train=False: moving statistics."""
         cx = ctx()
         with cx.variable_scope(name):
+            if not train:
+                return ops.batch_norm_eval(x, cx.var('gamma'), cx.var('beta'), cx.var('moving_mean'), cx.var('moving_variance'),
+                                           self._batch_norm_epsilon)
             tr = cx.trains()
             return ops.batch_norm_train(x, cx.var('gamma'), cx.var('beta'), cx.var('moving_mean'), cx.var('moving_variance'),
                                         self._batch_norm_epsilon, self._batch_norm_decay,
                                         gamma_grad=cx.var_grad('gamma') if tr else None, beta_grad=cx.var_grad('beta') if tr else None)
 
+    def _WN_dense(self, input_, output_size, scope, init_scale=1.0, init=False, activation=None, narrow=False):
+        """g * (x @ l2_normalize(V,[0])) + b (modle_base.py:50-73; the data-dependent init branch is never taken)."""
+        cx = ctx()
+        act, alpha = _act_of(activation)
+        with cx.variable_scope(scope):
+            tr = cx.trains()
+            return ops.conv2d(input_, cx.var('V'), cx.var('b'), output_size, 1, 1, 'SAME', act=act, alpha=alpha,
+                              wn=(cx.var('g'), cx.var_grad('g') if tr else None), kernel_grad=cx.var_grad('V') if tr else None,
+                              bias_grad=cx.var_grad('b') if tr else None, n_store_ld=(output_size, output_size) if narrow else None)
+
+    def _WN_conv2d(self, input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, padding='SAME', init_scale=1.0, init=False, name="conv2d",
+                   activation=None):
+        """g * conv(x, l2_normalize(V,[0,1,2])) + b (modle_base.py:75-108)."""
+        assert k_h == k_w and d_h == d_w
+        cx = ctx()
+        act, alpha = _act_of(activation)
+        with cx.variable_scope(name):
+            tr = cx.trains()
+            return ops.conv2d(input_, cx.var('V'), cx.var('b'), int(output_dim), k_h, d_h, padding, act=act, alpha=alpha,
+                              wn=(cx.var('g'), cx.var_grad('g') if tr else None), kernel_grad=cx.var_grad('V') if tr else None,
+                              bias_grad=cx.var_grad('b') if tr else None)
+
+    def _WN_deconv2d(self, input_, output_dim, k_h=3, k_w=3, d_h=2, d_w=2, padding='SAME', init_scale=1.0, init=False, name="deconv2d",
+                     activation=None, narrow=False):
+        """g * conv2d_transpose(x, l2_normalize(V,[0,1,3])) + b, V [kh,kw,Cout,Cin] (modle_base.py:130-155); 5x5 s2 'SAME' only
+        (the only configuration the reference's models use)."""
+        assert (k_h, k_w, d_h, d_w, padding) == (5, 5, 2, 2, 'SAME')
+        cx = ctx()
+        act, _ = _act_of(activation)
+        with cx.variable_scope(name):
+            tr = cx.trains()
+            return ops.deconv2d(input_, cx.var('V'), cx.var('b'), int(output_dim), act=act, kernel_grad=cx.var_grad('V') if tr else None,
+                                bias_grad=cx.var_grad('b') if tr else None, narrow_out=narrow,
+                                wn=(cx.var('g'), cx.var_grad('g') if tr else None))
+
+    def _nin(self, input, num_units, name, activation=None):
+        """network-in-network (1x1 conv): reshape + _WN_dense + reshape (modle_base.py:204-209)."""
+        return self._WN_dense(input, num_units, name, activation=activation)
+
     def _conv_cond_concat(self, x, y):
         """Concatenate conditioning vector on feature map axis (modle_base.py:239-244); y: Act [N,ncls]."""
         return ops.cond_concat(x, y.t, y.c)
 
-    def _drop_out(self, x, rate=0.5, train=False):
+    def _drop_out(self, x, rate=0.5, train=False, name=None):
         """tf.layers.dropout (modle_base.py:190-191): x*mask/keep with a floor(keep+U) keep-mask."""
         if not train:
             return x
         cx = ctx()
-        mask = cx.rng.keep_mask(cx, cx.next_rng_name('drop'), x.rows * x.c, 1.0 - rate)
+        mask = cx.rng.keep_mask(cx, name or cx.next_rng_name('drop'), x.rows * x.c, 1.0 - rate)
         assert x.ld == x.c
         return ops.scale_mask(x, mask, 1.0 / (1.0 - rate))
 
-    def _add_noise(self, inputs, mean=0.0, stddev=0.001, ld_out=None):
-        """inputs + N(mean, stddev) (modle_base.py:193-202); output channel-padded for the next conv."""
+    def _add_noise(self, inputs, mean=0.0, stddev=0.001, name=None):
+        """inputs + N(mean, stddev) (modle_base.py:193-202) on a dense activation; the gradient passes through."""
         assert mean == 0.0
         cx = ctx()
-        noise = cx.rng.normal(cx, 'noise', inputs.rows * inputs.c, stddev)
-        assert inputs.ld == inputs.c
-        from tg.runtime import pad32
-        return ops.pad_add(inputs, noise, pad32(inputs.c) if ld_out is None else ld_out)
+        noise = cx.rng.normal(cx, name or cx.next_rng_name('noise'), inputs.rows * inputs.c, stddev)
+        return ops.add_noise(inputs, noise)

@@ -96,15 +96,16 @@ class Train(Train_base):
         c, cx, m = self.config, self.cx, self.model
         with cx.phase_scope('D', train_nets=('discriminator',)):
             G = m.good_generator(self.z_g_ph, self.y_g_ph)
-            xz = m.zca().apply(concat_acts([self.x_u_c_ph, self.x_u_d_ph])) if c.DATA_NAME == 'cifar10' else \
-                concat_acts([self.x_u_c_ph, self.x_u_d_ph])
+            xz = concat_acts([m.as_image(self.x_u_c_ph), m.as_image(self.x_u_d_ph)])
+            if m.zca() is not None:
+                xz = m.zca().apply(xz)
             with cx.rng_scoped('D/C'):
                 c_logits, _ = m.classifier(xz, True, segments=[c.BATCH_SIZE_U_C, c.BATCH_SIZE_U_D])
             oh = ops.argmax_onehot(c_logits, c.NUM_CLASSES)                       # [C_unl_hard | C_unl_d_hard]
             k = c.NUM_CLASSES
             oh_unl = Act(oh[:c.BATCH_SIZE_U_C * k], c.BATCH_SIZE_U_C, 1, 1, k, k)
             oh_unl_d = Act(oh[c.BATCH_SIZE_U_C * k:], c.BATCH_SIZE_U_D, 1, 1, k, k)
-            ximg = concat_acts([self.x_l_d_ph, self.x_u_d_ph, G, self.x_u_c_ph])  # X_P | G | x_u_c   (:258-271)
+            ximg = concat_acts([m.as_image(a) for a in (self.x_l_d_ph, self.x_u_d_ph, G, self.x_u_c_ph)])   # X_P | G | x_u_c (:258-271)
             yall = concat_acts([self.y_l_d_ph, oh_unl_d, self.y_g_ph, oh_unl])
             with cx.rng_scoped('D/D'):
                 _, d_logits = m.discriminator(ximg, yall)
@@ -122,13 +123,13 @@ class Train(Train_base):
 
     def _c_forward_backward(self):
         c, cx, m = self.config, self.cx, self.model
-        cifar = c.DATA_NAME == 'cifar10'
+        rep = bool(getattr(m, 'CONSISTENCY', False))       # Good_GAN_cifar10 only: second stochastic pass on x_u_c
         with cx.phase_scope('C', train_nets=('classifier',)):
             G = m.good_generator(self.z_g_ph, self.y_g_ph)
-            parts = [self.x_l_c_ph, self.x_u_c_ph] + ([self.x_u_c_ph] if cifar else []) + [G]
+            parts = [self.x_l_c_ph, self.x_u_c_ph] + ([self.x_u_c_ph] if rep else []) + [G]
             segs = [p.n for p in parts]
-            xc = concat_acts(parts)
-            if cifar:
+            xc = concat_acts([m.as_image(p) for p in parts])
+            if m.zca() is not None:
                 xc = m.zca().apply(xc)
             with cx.rng_scoped('C/C'):
                 c_logits, _ = m.classifier(xc, True, segments=segs)
@@ -137,7 +138,7 @@ class Train(Train_base):
             oh_unl = Act(ops.argmax_onehot(c_unl, k), c_unl.n, 1, 1, k, k)
             with cx.rng_scoped('C/D'):
                 _, d_unl = m.discriminator(self.x_u_c_ph, oh_unl)
-            self._c_loss(c_logits, segs[0], segs[1], segs[1] if cifar else 0, G.n, self.y_l_c_ph, self.y_g_ph, d_unl,
+            self._c_loss(c_logits, segs[0], segs[1], segs[1] if rep else 0, G.n, self.y_l_c_ph, self.y_g_ph, d_unl,
                          self.hyper[2:4], self.loss_dev[2:3])
             cx.backward()
 
@@ -226,8 +227,8 @@ class Train(Train_base):
             with cx.phase_scope('val', record=False):
                 xa = cx.from_numpy(x, key='val:x')
                 ya = cx.from_numpy(y, key='val:y')
-                if c.DATA_NAME == 'cifar10':
-                    xa = m.zca().apply(xa)
+                if m.zca() is not None:
+                    xa = m.zca().apply(m.as_image(xa))
                 with cx.rng_scoped('val/C'):
                     logits, _ = m.classifier(xa, False)
                 lib.call('tg_accuracy_count_f32', logits.ptr, logits.ld, ya.ptr, logits.n, c.NUM_CLASSES, lib.ptr(counters), cx.stream)
@@ -258,7 +259,7 @@ class Train(Train_base):
         iters = int(c.TRAIN_SIZE / c.BATCH_SIZE)
         for epoch in range(1, c.EPOCHS + 1):
             lambda_1 = c.FAKE_G_LAMBDA if (start_epoch + epoch) > 200 else 0.          # :165
-            lambda_2 = (0.5 if epoch > 67 else 0.) if c.DATA_NAME == 'cifar10' else 0.  # :171
+            lambda_2 = (0.5 if epoch > 67 else 0.) if getattr(self.model, 'CONSISTENCY', False) else 0.  # :171
             if start_epoch + epoch >= 300:                                             # :175-177
                 lr, cla_lr = lr * 0.995, cla_lr * 0.99
             self.set_hyper(lr, cla_lr, lambda_1, lambda_2)

@@ -248,6 +248,15 @@ __global__ void bn_finalize(const float* __restrict__ s1, const float* __restric
   }
 }
 
+__global__ void bn_eval_finalize(int c, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mm,
+                                 const float* __restrict__ mv, float eps, float* __restrict__ scale, float* __restrict__ shift) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  const float sc = gamma[col] / sqrtf(mv[col] + eps);
+  scale[col] = sc;
+  shift[col] = beta[col] - mm[col] * sc;
+}
+
 __global__ void bn_bwd_finalize(const float* __restrict__ s_dy, const float* __restrict__ s_dyx, int rows, int c, const float* __restrict__ gamma,
                                 const float* __restrict__ mean_inv, float* __restrict__ abc, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,7 +311,7 @@ int tg_colstats_f32(int mode, const float* a, int ld_a, const float* b, int ld_b
   if (rc != TG_OK) return rc;
   TG_REQUIRE(a && workspace && s1, "colstats: null buffer");
   TG_REQUIRE(ld_a % 4 == 0 && (b == nullptr || ld_b % 4 == 0), "colstats: ld must be a multiple of 4");
-  TG_REQUIRE(mode != 4 || (nseg == 1 && c % 4 == 0), "colstats: mode 4 needs one segment and c %% 4 == 0");
+  TG_REQUIRE(mode != 4 || nseg == 1, "colstats: mode 4 needs one segment");   // b must hold (c+3)/4*4 readable floats
   TG_REQUIRE((mode == 0 || mode == 1) || b != nullptr, "colstats: mode %d needs operand b", mode);
   const int c4 = (c + 3) / 4, c_pad = c4 * 4;
   TG_REQUIRE(c_pad <= ld_a && (b == nullptr || mode == 4 || c_pad <= ld_b), "colstats: c=%d exceeds ld", c);
@@ -402,6 +411,16 @@ int tg_bn_finalize_f32(const float* s1, const float* s2, int rows, int c, const 
   hipLaunchKernelGGL(bn_finalize, dim3((c + 127) / 128), dim3(128), 0, s, s1, s2, rows, c, gamma, beta, eps, scale, shift, mean_inv, moving_mean,
                      moving_var, decay, bessel);
   TG_CHECK_LAUNCH("bn_finalize");
+  return TG_OK;
+}
+
+int tg_bn_eval_finalize_f32(int c, const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps,
+                            float* scale, float* shift, void* stream) {
+  TG_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift && c > 0, "bn_eval_finalize: bad args");
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 0, s);
+  hipLaunchKernelGGL(bn_eval_finalize, dim3((c + 127) / 128), dim3(128), 0, s, c, gamma, beta, moving_mean, moving_var, eps, scale, shift);
+  TG_CHECK_LAUNCH("bn_eval_finalize");
   return TG_OK;
 }
 

@@ -77,8 +77,9 @@ __global__ void __launch_bounds__(256) wn_bwd_apply(const float* __restrict__ dw
 // src [T][A][B] (B contiguous), optional per-b scale.
 //   dst_same[t][a][b]      padded copy  [T][A_pad][B_pad]
 //   dst_tr  [b*sb + t*st + a]           (a contiguous; rows b < B_pad, a < A_pad, zero padded)
-__global__ void __launch_bounds__(256) filter_prep(const float* __restrict__ src, const float* __restrict__ scale, int a_dim, int b_dim, int a_pad, int b_pad,
-                                                   float* __restrict__ dst_same, float* __restrict__ dst_tr, int64_t sb, int64_t st) {
+__global__ void __launch_bounds__(256) filter_prep(const float* __restrict__ src, const float* __restrict__ scale, const float* __restrict__ scale_a,
+                                                   int a_dim, int b_dim, int a_pad, int b_pad, float* __restrict__ dst_same, float* __restrict__ dst_tr,
+                                                   int64_t sb, int64_t st) {
   __shared__ float tile[32][33];
   const int t = blockIdx.z, a0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -88,6 +89,7 @@ __global__ void __launch_bounds__(256) filter_prep(const float* __restrict__ src
     if (a < a_dim && b < b_dim) {
       v = src[((int64_t)t * a_dim + a) * b_dim + b];
       if (scale) v *= scale[b];
+      if (scale_a) v *= scale_a[a];
     }
     tile[i][tx] = v;
     if (dst_same && a < a_pad && b < b_pad) dst_same[((int64_t)t * a_pad + a) * b_pad + b] = v;
@@ -117,6 +119,51 @@ __global__ void __launch_bounds__(256) slab_reduce(const float* __restrict__ sla
   }
 }
 
+// weight norm of a transposed-conv filter V[t][a][b] = [kh*kw][Cout][Cin]: the norm runs over axes (0,1,3) = (t, b) for
+// every output channel a (Model/modle_base.py:148).  One workgroup per output channel (Cout is 3 in the reference).
+__device__ float block_sum256(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) wn_scale_tab(const float* __restrict__ v, const float* __restrict__ g, int t_dim, int a_dim, int b_dim,
+                                                    float* __restrict__ scale) {
+  __shared__ float red[4];
+  const int a = blockIdx.x;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < t_dim * b_dim; i += 256) {
+    const float x = v[((int64_t)(i / b_dim) * a_dim + a) * b_dim + i % b_dim];
+    ss += x * x;
+  }
+  ss = block_sum256(ss, red);
+  if (threadIdx.x == 0) scale[a] = g[a] * rsqrtf(fmaxf(ss, 1e-12f));
+}
+
+__global__ void __launch_bounds__(256) wn_bwd_tab(const float* __restrict__ dw, const float* __restrict__ v, const float* __restrict__ g, int t_dim, int a_dim,
+                                                  int b_dim, float* __restrict__ dv, float* __restrict__ dg) {
+  __shared__ float red[4];
+  const int a = blockIdx.x;
+  float dot = 0.f, ss = 0.f;
+  for (int i = threadIdx.x; i < t_dim * b_dim; i += 256) {
+    const int64_t idx = ((int64_t)(i / b_dim) * a_dim + a) * b_dim + i % b_dim;
+    dot += dw[idx] * v[idx];
+    ss += v[idx] * v[idx];
+  }
+  dot = block_sum256(dot, red);
+  ss = block_sum256(ss, red);
+  const float nrm = sqrtf(ss);
+  if (threadIdx.x == 0) dg[a] = dot / nrm;
+  const float c0 = g[a] / nrm, c1 = dot / ss;
+  for (int i = threadIdx.x; i < t_dim * b_dim; i += 256) {
+    const int64_t idx = ((int64_t)(i / b_dim) * a_dim + a) * b_dim + i % b_dim;
+    dv[idx] = c0 * (dw[idx] - v[idx] * c1);
+  }
+}
+
 int ew_grid(int64_t work) {
   int64_t b = (work + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -135,13 +182,13 @@ int tg_wn_scale_f32(const float* v, const float* g, int rows, int c, float* scal
   return TG_OK;
 }
 
-int tg_filter_prep_f32(const float* src, const float* scale, int t, int a, int b, int a_pad, int b_pad, float* dst_same, float* dst_tr, int64_t tr_sb,
-                       int64_t tr_st, void* stream) {
+int tg_filter_prep_f32(const float* src, const float* scale, const float* scale_a, int t, int a, int b, int a_pad, int b_pad, float* dst_same,
+                       float* dst_tr, int64_t tr_sb, int64_t tr_st, void* stream) {
   TG_REQUIRE(src && (dst_same || dst_tr) && t > 0 && a > 0 && b > 0 && a_pad >= a && b_pad >= b, "filter_prep: bad args");
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * t * ((double)a * b + (double)a_pad * b_pad * ((dst_same ? 1 : 0) + (dst_tr ? 1 : 0))), s);
-  hipLaunchKernelGGL(filter_prep, dim3((a_pad + 31) / 32, (b_pad + 31) / 32, t), dim3(256), 0, s, src, scale, a, b, a_pad, b_pad, dst_same, dst_tr,
-                     tr_sb, tr_st);
+  hipLaunchKernelGGL(filter_prep, dim3((a_pad + 31) / 32, (b_pad + 31) / 32, t), dim3(256), 0, s, src, scale, scale_a, a, b, a_pad, b_pad, dst_same,
+                     dst_tr, tr_sb, tr_st);
   TG_CHECK_LAUNCH("filter_prep");
   return TG_OK;
 }
@@ -152,6 +199,24 @@ int tg_slab_reduce_f32(const float* slab, int n_split, int t, int c_pad, int n_p
   tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * t * c * n * (n_split + 1), s);
   hipLaunchKernelGGL(slab_reduce, dim3(ew_grid((int64_t)t * c * n)), dim3(256), 0, s, slab, n_split, t, c_pad, n_pad, c, n, dst);
   TG_CHECK_LAUNCH("slab_reduce");
+  return TG_OK;
+}
+
+int tg_wn_scale_tab_f32(const float* v, const float* g, int t, int a, int b, float* scale_a, void* stream) {
+  TG_REQUIRE(v && g && scale_a && t > 0 && a > 0 && b > 0, "wn_scale_tab: bad args");
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * t * a * b, s);
+  hipLaunchKernelGGL(wn_scale_tab, dim3(a), dim3(256), 0, s, v, g, t, a, b, scale_a);
+  TG_CHECK_LAUNCH("wn_scale_tab");
+  return TG_OK;
+}
+
+int tg_wn_bwd_tab_f32(const float* dw, const float* v, const float* g, int t, int a, int b, float* dv, float* dg, void* stream) {
+  TG_REQUIRE(dw && v && g && dv && dg && t > 0 && a > 0 && b > 0, "wn_bwd_tab: bad args");
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * t * a * b * 5, s);
+  hipLaunchKernelGGL(wn_bwd_tab, dim3(a), dim3(256), 0, s, dw, v, g, t, a, b, dv, dg);
+  TG_CHECK_LAUNCH("wn_bwd_tab");
   return TG_OK;
 }
 

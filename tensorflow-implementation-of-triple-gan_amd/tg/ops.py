@@ -32,9 +32,9 @@ def colstats(mode, a_t, ld_a, b_t, ld_b, rows, c, seg_rows, act=None, alpha=0.2,
     wsn = _call('tg_colstats_workspace_floats', rows, nseg, c)
     work = cx.scratch('cs', wsn)
     if s1 is None:
-        s1 = cx.scratch('s1_', nseg * c)
+        s1 = cx.scratch('s1_', nseg * c + 4)          # +4: mode 4 reads its per-channel input in 16-B groups
     if s2 is None and mode in (1, 3):
-        s2 = cx.scratch('s2_', nseg * c)
+        s2 = cx.scratch('s2_', nseg * c + 4)
     _call('tg_colstats_f32', mode, _p(a_t), ld_a, _p(b_t), ld_b, rows, c, seg_array(seg_rows), nseg, ACT[act], alpha,
           _p(work), _p(s1), _p(s2), cx.stream)
     return s1, s2
@@ -79,7 +79,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
         _call('tg_wn_scale_f32', _p(kernel), _p(wn[0]), t * c_in, c_out, _p(scale), cx.stream)
     w_oti = cx.scratch('woti', co_p * t * ci_p)
     w_hwio = cx.scratch('whwio', t * ci_p * co_p) if needs_x else None
-    _call('tg_filter_prep_f32', _p(kernel), _p(scale), t, c_in, c_out, ci_p, co_p, _p(w_hwio), _p(w_oti), t * ci_p, ci_p, cx.stream)
+    _call('tg_filter_prep_f32', _p(kernel), _p(scale), None, t, c_in, c_out, ci_p, co_p, _p(w_hwio), _p(w_oti), t * ci_p, ci_p, cx.stream)
     if n_store_ld is None:
         n_store, ld_out = c_out, co_p
     else:
@@ -144,17 +144,22 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     return y
 
 
-def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None, narrow_out=False):
+def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None, narrow_out=False, wn=None):
     """tf.layers.conv2d_transpose 5x5 s2 'same' + bias + act (Model/modle_base.py:246-259);
-    kernel [5,5,c_out,c_in].  narrow_out: store only the logical channels (generator output)."""
+    kernel [5,5,c_out,c_in].  narrow_out: store only the logical channels (generator output).
+    wn=(g, g_grad): W = g * l2_normalize(V,[0,1,3]) (NN_Base._WN_deconv2d, Model/modle_base.py:130-155)."""
     cx = ctx()
     assert x.ld % 32 == 0
     c_in, ci_p, co_p = x.c, x.ld, pad32(c_out)
     needs_w = cx.trains() and kernel_grad is not None
     needs_x = cx.tape is not None and x.requires_grad
+    scale_a = None
+    if wn is not None:
+        scale_a = cx.scratch('wnsa', c_out)
+        _call('tg_wn_scale_tab_f32', _p(kernel), _p(wn[0]), 25, c_out, c_in, _p(scale_a), cx.stream)
     w_pad = cx.scratch('wpad', 25 * co_p * ci_p)
     w_tr = cx.scratch('wtr', 25 * ci_p * co_p) if needs_x else None
-    _call('tg_filter_prep_f32', _p(kernel), None, 25, c_out, c_in, co_p, ci_p, _p(w_pad), _p(w_tr), co_p, ci_p * co_p, cx.stream)
+    _call('tg_filter_prep_f32', _p(kernel), None, _p(scale_a), 25, c_out, c_in, co_p, ci_p, _p(w_pad), _p(w_tr), co_p, ci_p * co_p, cx.stream)
     ld_out = c_out if narrow_out else co_p
     y = cx.new_act(x.n, 2 * x.h, 2 * x.w, c_out, ld_out, requires_grad=needs_w or needs_x)
     dds = lib.desc_array(geom.deconv_fwd(x.n, x.h, x.w, ci_p, co_p, ld_out=ld_out, n_store=c_out, act=act))
@@ -171,7 +176,12 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
         if needs_w:
             if bias_grad is not None:
                 colstats(0, dpre, co_p, None, 0, y.rows, c_out, [y.rows], s1=bias_grad)
-            filter_grad(geom.deconv_wgrad(x.n, x.h, x.w, co_p, ci_p), dpre, x.t, 25, c_out, c_in, kernel_grad)
+            if wn is None:
+                filter_grad(geom.deconv_wgrad(x.n, x.h, x.w, co_p, ci_p), dpre, x.t, 25, c_out, c_in, kernel_grad)
+            else:
+                dw = cx.scratch('dw', 25 * c_out * c_in)
+                filter_grad(geom.deconv_wgrad(x.n, x.h, x.w, co_p, ci_p), dpre, x.t, 25, c_out, c_in, dw)
+                _call('tg_wn_bwd_tab_f32', _p(dw), _p(kernel), _p(wn[0]), 25, c_out, c_in, _p(kernel_grad), _p(wn[1]), cx.stream)
         if needs_x:
             gx = cx.grad_of(x)
             _call('tg_igemm_f32', geom.deconv_dgrad(x.n, x.h, x.w, ci_p, co_p, ld_out=gx.ld, n_store=ci_p), _p(dpre), _p(w_tr), None,
@@ -182,6 +192,18 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
 
 
 # ------------------------------------------------------------------ batch norm (tf.contrib.layers.batch_norm, training mode)
+
+def batch_norm_eval(x, gamma, beta, mm, mv, eps):
+    """contrib batch_norm with is_training=False: y = gamma*(x-moving_mean)/sqrt(moving_var+eps)+beta (no tape: evaluation only)."""
+    cx = ctx()
+    c = x.c
+    scale, shift = cx.scratch('bnsc', c), cx.scratch('bnsh', c)
+    _call('tg_bn_eval_finalize_f32', c, _p(gamma), _p(beta), _p(mm), _p(mv), eps, _p(scale), _p(shift), cx.stream)
+    y = cx.new_act(x.n, x.h, x.w, c, x.ld)
+    _call('tg_seg_scale_shift_act_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, c, seg_array([x.rows]), 1, _p(scale), _p(shift), 0, 0.0,
+          cx.stream)
+    return y
+
 
 def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_grad=None, relu_input=False):
     """y = gamma*(x-mu)/sqrt(var+eps)+beta over all rows (Model/modle_base.py:229-237).
@@ -195,7 +217,7 @@ def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_g
     s2, _ = colstats(4, x.t, x.ld, s1, 0, x.rows, c, [x.rows], alpha=1.0 / x.rows)   # centred second pass (tf.nn.moments)
     scale, shift, mean_inv = cx.scratch('bnsc', c), cx.scratch('bnsh', c), cx.scratch('bnmi', 2 * c)
     _call('tg_bn_finalize_f32', _p(s1), _p(s2), x.rows, c, _p(gamma), _p(beta), eps, _p(scale), _p(shift), _p(mean_inv), _p(mm), _p(mv),
-          decay, 1 if (x.h * x.w > 1) else 0, cx.stream)
+          decay, 1, cx.stream)
     y = cx.new_act(x.n, x.h, x.w, c, x.ld, requires_grad=needs)
     _call('tg_seg_scale_shift_act_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, c, seg_array([x.rows]), 1, _p(scale), _p(shift), 0, 0.0,
           cx.stream)
@@ -310,6 +332,12 @@ def argmax_onehot(logits, k):
     return out
 
 
+def copy2d(dst_t, ld_d, dst_col, src_t, ld_s, rows, c):
+    """dst[r][dst_col : dst_col+c] = src[r][:c] (strided device copy)."""
+    cx = ctx()
+    _call('tg_copy2d_f32', C.c_void_p(src_t.data_ptr()), ld_s, C.c_void_p(dst_t.data_ptr() + 4 * dst_col), ld_d, rows, c, cx.stream)
+
+
 def copy_rows(dst_t, dst_off, src_t, numel):
     """contiguous device copy (batch concatenation along N)."""
     cx = ctx()
@@ -327,3 +355,51 @@ def reshape(x, n, h, w, c):
             x.grad = Act(g.t, x.n, x.h, x.w, x.c, x.c)
         cx.record(bwd)
     return y
+
+
+def add_noise(x, noise_t):
+    """x + noise on a dense activation (NN_Base._add_noise, Model/modle_base.py:193-202); the gradient passes through."""
+    cx = ctx()
+    y = cx.new_act(x.n, x.h, x.w, x.c, x.ld, requires_grad=x.requires_grad)
+    _call('tg_pad_add_f32', x.ptr, x.ld, x.c, _p(noise_t), x.c, y.ptr, y.ld, x.rows, cx.stream)
+    if cx.tape is not None and x.requires_grad:
+        def bwd():
+            x.grad = y.grad
+        cx.record(bwd)
+    return y
+
+
+def global_avgpool(x):
+    """tf.reduce_mean(x, axis=[1,2]) (Model/Good_GAN.py:198,346) -> [N,C]."""
+    cx = ctx()
+    out = cx.new_act(x.n, 1, 1, x.c, pad32(x.c), requires_grad=x.requires_grad)
+    _call('tg_gavgpool_concat_f32', x.ptr, x.ld, x.c, None, 0, out.ptr, out.ld, x.n, x.h * x.w, cx.stream)
+    if cx.tape is not None and x.requires_grad:
+        def bwd():
+            gx = cx.grad_of(x)
+            _call('tg_gavgpool_bwd_f32', out.grad.ptr, out.grad.ld, x.ptr, x.ld, gx.ptr, gx.ld, x.n, x.h * x.w, x.c, 0, 0.0, cx.stream)
+        cx.record(bwd)
+    return out
+
+
+def view(x, h, w, c):
+    """reinterpret a dense activation's per-image shape (tf.reshape), gradients share storage."""
+    return reshape(x, x.n, h, w, c)
+
+
+def concat_batch(acts):
+    """tf.concat(acts, 0) of network OUTPUTS: the parts receive views of the concatenated gradient."""
+    from .batching import concat_acts
+    cx = ctx()
+    out = concat_acts(acts)
+    out.requires_grad = any(a.requires_grad for a in acts)
+    if cx.tape is not None and out.requires_grad:
+        def bwd():
+            if out.grad is None:          # e.g. the concatenated features: no loss term of Train_goodGAN.py uses them
+                return
+            off = 0
+            for a in acts:
+                a.grad = out.grad.view_rows(off, off + a.n)
+                off += a.n
+        cx.record(bwd)
+    return out

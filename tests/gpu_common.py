@@ -46,16 +46,51 @@ def zca():
     return _STATE['zca']
 
 
-def fresh_trainer(config, params=None):
+def make_config_goodgan(data, sizes, **over):
+    """MNIST / SVHN experiment configs of Training/Train_goodGAN.py:484-530,641-685 at the given batch sizes."""
+    from config import Config
+    hw, ch = (28, 1) if data == 'mnist' else (32, 3)
+
+    class TempConfig(Config):
+        NAME = "Good_GAN"
+        DATA_NAME = data
+        DATA_DIR = "/nonexistent"
+        NUM_LABEL = 100 if data == 'mnist' else 1000
+        BATCH_SIZE_G = sizes['B_G']
+        BATCH_SIZE_L_C = sizes['L_C']
+        BATCH_SIZE_U_C = sizes['U_C']
+        BATCH_SIZE_L_D = sizes['L_D']
+        BATCH_SIZE_U_D = sizes['U_D']
+        BATCH_SIZE = sizes['B_G']
+        IMAGE_HEIGHT, IMAGE_WIDTH, CHANNEL = hw, hw, ch
+        FAKE_G_LAMBDA = 0.1
+        Z_DIM = 100
+        NUM_CLASSES = 10
+        MINIBATCH_DIS = False
+        LEARNING_RATE = 1e-3 if data == 'mnist' else 3e-4
+        CLA_LEARNINIG_RATE = 3e-4
+        EPOCHS = 1
+        TRAIN_SIZE = 1000
+        SUMMARY = False
+        USE_HIP_GRAPH = False
+
+    c = TempConfig()
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def fresh_trainer(config, params=None, Model=None):
     """new Context + Train + model; optionally load an oracle parameter dict."""
     import torch
     from tg import runtime
     from Training.Train_goodGAN import Train
-    from Model.Good_GAN_cifar10 import Good_GAN_cifar10
+    if Model is None:
+        from Model.Good_GAN_cifar10 import Good_GAN_cifar10 as Model
     runtime.set_context(None)
     torch.cuda.empty_cache()
     tr = Train(config, None, None)
-    tr._build_train_graph(Good_GAN_cifar10)
+    tr._build_train_graph(Model)
     if params is not None:
         for st in tr.cx.stores.values():
             st.load_dict(params)
@@ -87,3 +122,21 @@ def injected_arrays(rnd):
 def rel_err(a, ref):
     a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
     return np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30)
+
+
+def injected_arrays_goodgan(rnd):
+    """oracle rnd of one Good_GAN iteration -> '<rng scope>/<name>' arrays (classifier applications run one by one)."""
+    out = {}
+    for i, key in enumerate(('C_unl', 'C_unl_d')):
+        for k, v in rnd['D'][key].items():
+            out['D/C/s%d/%s' % (i, k)] = v
+    for k, v in cat_rnd(rnd['D']['D_real'], rnd['D']['D_fake'], rnd['D']['D_unl']).items():
+        out['D/D/' + k] = v
+    for k, v in rnd['G']['D_fake'].items():
+        out['G/D/' + k] = v
+    for i, key in enumerate(('C_real', 'C_unl', 'C_fake')):
+        for k, v in rnd['C'][key].items():
+            out['C/C/s%d/%s' % (i, k)] = v
+    for k, v in rnd['C']['D_unl'].items():
+        out['C/D/' + k] = v
+    return out

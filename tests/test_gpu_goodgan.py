@@ -1,0 +1,141 @@
+"""GPU parity of the MNIST and SVHN models of Model/Good_GAN.py (generator, discriminator, classifier: forward,
+all parameter gradients, evaluation mode) and of one phase-synchronised Triple-GAN iteration, against the float64
+oracle (oracle/nets_goodgan.py, oracle/step_goodgan.py) with identical parameters and injected randomness."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets_goodgan as N
+from oracle import step_goodgan as S
+import gpu_common as G
+from test_oracle_goodgan import scrambled
+
+pytestmark = pytest.mark.gpu
+ACT_TOL, GRAD_L2, GRAD_MAX = 2e-4, 1e-2, 5e-2
+NETS = {'D': 'discriminator', 'G': 'good_generator', 'C': 'classifier'}
+SMALL = dict(B_G=6, L_C=4, U_C=4, L_D=2, U_D=4)
+
+
+def f64(d):
+    return {k: (f64(v) if isinstance(v, dict) else np.asarray(v, np.float64)) for k, v in d.items()}
+
+
+def trainer(data, P, sizes=SMALL):
+    from Model.Good_GAN import Good_GAN
+    return G.fresh_trainer(G.make_config_goodgan(data, sizes), {k: v.astype(np.float32) for k, v in P.items()}, Good_GAN)
+
+
+def check_grads(store, gref, gmax_floor=1e-4):
+    gmax = max(np.abs(v).max() for v in gref.values())
+    for k, ref in gref.items():
+        d = store.get(k, 'grad') - ref
+        sc = max(np.abs(ref).max(), gmax_floor * gmax)        # biases in front of a batch norm have analytically zero gradients: fp32 noise
+        assert np.abs(d).max() <= GRAD_MAX * sc, ('max', k, np.abs(d).max(), sc)
+        assert np.linalg.norm(d) <= GRAD_L2 * max(np.linalg.norm(ref), sc), ('L2', k)
+
+
+@pytest.mark.parametrize("data", ['mnist', 'svhn'])
+def test_networks_forward_backward(data):
+    from tg.runtime import InjectedRNG
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in scrambled(data, 3).items()}
+    tr = trainer(data, P)
+    cx, m = tr.cx, tr.model
+    n = 5
+    sizes = dict(B_G=n, L_C=n, U_C=n, L_D=1, U_D=n - 1)
+    b = f64(S.synth_batch(data, 5, sizes))
+    rnd = S.synth_rnd(data, 6, sizes)
+    rng = np.random.default_rng(7)
+    # ---- generator
+    out, gc, _ = N.seq_fwd(P, N.generator_layers(data), b['z_g'], b['y_g'], {}, True)
+    do = rng.standard_normal(out.shape).astype(np.float32)
+    gref, _ = N.seq_bwd(P, N.generator_layers(data), gc, do.astype(np.float64), b['y_g'], {})
+    with cx.phase_scope('Tg', train_nets=('good_generator',)):
+        o = m.good_generator(cx.from_numpy(b['z_g']), cx.from_numpy(b['y_g']))
+        o.grad = cx.from_numpy(do.reshape(o.numpy().shape))
+        cx.backward()
+    assert G.rel_err(o.numpy().reshape(out.shape), out) < ACT_TOL
+    check_grads(cx.stores['good_generator'], gref)
+    # ---- discriminator (weights and input gradient)
+    r = rnd['G']['D_fake']
+    img = b['x_l_c']
+    logits, dc, _ = N.seq_fwd(P, N.discriminator_layers(data), img, b['y_l_c'], f64(r), True)
+    dl = rng.standard_normal(logits.shape).astype(np.float32)
+    gref, dimg = N.seq_bwd(P, N.discriminator_layers(data), dc, dl.astype(np.float64), b['y_l_c'], f64(r))
+    cx.rng = InjectedRNG({'Td/D/' + k: v for k, v in r.items()}, cx.device)
+    with cx.phase_scope('Td', train_nets=('discriminator',)):
+        ia = cx.from_numpy(img)
+        ia.requires_grad = True
+        with cx.rng_scoped('Td/D'):
+            _, lg = m.discriminator(ia, cx.from_numpy(b['y_l_c']))
+        lg.grad = cx.from_numpy(dl, ld=32)
+        cx.backward()
+    assert G.rel_err(lg.numpy(), logits) < ACT_TOL
+    check_grads(cx.stores['discriminator'], gref)
+    assert G.rel_err(ia.grad.numpy().reshape(dimg.shape), dimg) < GRAD_MAX
+    # ---- classifier: training mode (gradients, moving statistics) and evaluation mode
+    r = rnd['C']['C_real']
+    CL = N.classifier_layers(data)
+    bnu = {}
+    logits, cc, feat = N.seq_fwd(P, CL, b['x_l_c'], None, f64(r), True, bnu)
+    dl = rng.standard_normal(logits.shape).astype(np.float32)
+    gref, _ = N.seq_bwd(P, CL, cc, dl.astype(np.float64), None, f64(r))
+    cx.rng = InjectedRNG({'Tc/C/' + k: v for k, v in r.items()}, cx.device)
+    with cx.phase_scope('Tc', train_nets=('classifier',)):
+        with cx.rng_scoped('Tc/C'):
+            lg, fm = m.classifier(cx.from_numpy(b['x_l_c']), True)
+        lg.grad = cx.from_numpy(dl, ld=32)
+        cx.backward()
+    assert G.rel_err(lg.numpy(), logits) < ACT_TOL and G.rel_err(fm.numpy(), feat) < ACT_TOL
+    check_grads(cx.stores['classifier'], gref)
+    st = cx.stores['classifier']
+    for name, (mm, mv) in bnu.items():
+        assert G.rel_err(st.get(name + '/moving_mean'), mm) < ACT_TOL, name
+        assert G.rel_err(st.get(name + '/moving_variance'), mv) < ACT_TOL, name
+    P2 = dict(P)
+    N.commit_bn(P2, bnu)
+    le, _, _ = N.seq_fwd(P2, CL, b['x_l_c'], None, f64(r), False)
+    with cx.phase_scope('Te', record=False):
+        with cx.rng_scoped('Tc/C'):
+            lge, _ = m.classifier(cx.from_numpy(b['x_l_c']), False)
+    assert G.rel_err(lge.numpy(), le) < ACT_TOL
+
+
+@pytest.mark.parametrize("data", ['mnist', 'svhn'])
+def test_synchronised_iteration(data):
+    from tg.runtime import InjectedRNG
+    P32 = {k: v.astype(np.float32) for k, v in scrambled(data, 11).items()}
+    st = S.new_state(f64(P32))
+    tr = trainer(data, f64(P32))
+    hyper = dict(lr=1e-3, cla_lr=3e-4, beta1=0.5, lambda_1=0.1, lambda_2=0.0)
+    tr.set_hyper(hyper['lr'], hyper['cla_lr'], hyper['lambda_1'], 0.0)
+    cx, stores = tr.cx, tr.cx.stores
+    b, rnd = S.synth_batch(data, 21, SMALL), S.synth_rnd(data, 22, SMALL)
+    b64, r64 = f64(b), f64(rnd)
+    cx.rng = InjectedRNG(G.injected_arrays_goodgan(rnd), cx.device)
+    tr.feed(b)
+
+    def sync(net):
+        for k in stores[net].names():
+            stores[net].set(k, st['P'][k])
+
+    d_ref = S.d_phase(st, data, b64, r64['D'], hyper)
+    tr._d_forward_backward()
+    check_grads(stores['discriminator'], st['last_grads']['D'])
+    tr._train_op(tr.d_optimizer, stores['discriminator'])
+    for net in NETS.values():
+        sync(net)                                  # includes the classifier / generator moving statistics
+    g_ref = S.g_phase(st, data, b64, r64['G'], hyper)
+    tr._g_forward_backward()
+    check_grads(stores['good_generator'], st['last_grads']['G'])
+    tr._train_op(tr.g_optimizer, stores['good_generator'])
+    for net in NETS.values():
+        sync(net)
+    c_ref = S.c_phase(st, data, b64, r64['C'], hyper)
+    tr._c_forward_backward()
+    check_grads(stores['classifier'], st['last_grads']['C'])
+    tr._c_apply()
+    for r, g in zip((d_ref, g_ref, c_ref), tr.losses()):
+        assert abs(r - g) <= 5e-4 * max(1.0, abs(r)), ((d_ref, g_ref, c_ref), tr.losses())
+    cs = stores['classifier']
+    for k in cs.names(False):                      # classifier moving statistics after its three training applications
+        assert G.rel_err(cs.get(k), st['P'][k]) < 1e-3, k
