@@ -28,7 +28,23 @@ namespace {
 constexpr int BK = 32;    // reduction depth per LDS tile
 constexpr int LDT = 36;   // padded LDS row stride (floats)
 
-constexpr int MAX_SUB = 4;   // sub-problems per launch (the 4 output parities of a stride-2 transposed conv / dgrad)
+#ifdef TG_STAMP
+// Diagnostic build (never shipped): per-phase cycle sums of the K loop for a few workgroups, wave 0, read back with
+// tg_debug_read_stamps.  Stamp values go only to this buffer; no output depends on them.
+__device__ unsigned long long tg_stamps[8 * 8];
+__device__ unsigned long long tg_block_times[3 * 8192];   // per workgroup: start, end (s_memrealtime, 100 MHz), HW ids
+#define STAMP(var)                                                                 \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");    \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+  } while (0)
+#else
+#define STAMP(var) do {} while (0)
+#endif
+
+constexpr int MAX_SUB = 4;
+constexpr uint32_t OOB_OFF = 0x80000000u;   // byte offset beyond any (< 2 GiB) tensor: buffer loads return 0, stores are dropped   // sub-problems per launch (the 4 output parities of a stride-2 transposed conv / dgrad)
 
 // kernel-side view of one tg_igemm_desc: tap tables repacked to one dword per tap so that the (block-uniform) tap
 // lookup is a scalar s_load_dword — int8/int16 arrays indexed dynamically compile to VECTOR byte loads plus a
@@ -48,7 +64,7 @@ struct IgemmParams {
   int64_t w_sn, w_st;
   int n_img, h_in, w_in, ld_in, c_out;
   int n_sub, M, m_tiles, n_tiles;
-  uint32_t in_bytes;
+  uint32_t in_bytes, w_bytes, out_bytes;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -85,6 +101,11 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   int* t_out = t_x + BM;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef TG_STAMP
+  unsigned long long t_entry = 0;
+  STAMP(t_entry);
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int per_sub = p.m_tiles * p.n_tiles;
   const int lid = xcd_remap(blockIdx.x, per_sub * p.n_sub);
   const int sub = lid / per_sub, rem_id = lid - sub * per_sub;
@@ -94,7 +115,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
 
   if (tid < BM) {
     int m = m0 + tid;
-    int base = 0, y0 = -30000, x0 = 0, oo = -1;
+    int base = 0, y0 = -30000, x0 = 0, oo = (int)0x80000000;   // masked row: out-of-range byte offset
     if (m < p.M) {
       int hw = d.h_v * d.w_v;
       int img = m / hw, rem = m - img * hw;
@@ -102,7 +123,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       base = img * p.h_in * p.w_in * p.ld_in;
       y0 = vy * d.s_y;
       x0 = vx * d.s_x;
-      oo = ((img * d.h_out + vy * d.os_y + d.oo_y) * d.w_out + vx * d.os_x + d.oo_x) * d.ld_out;
+      oo = ((img * d.h_out + vy * d.os_y + d.oo_y) * d.w_out + vx * d.os_x + d.oo_x) * d.ld_out * 4;   // byte offset
     }
     t_base[tid] = base; t_y[tid] = y0; t_x[tid] = x0; t_out[tid] = oo;
   }
@@ -115,34 +136,45 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     int r = lrow + 32 * j;
     abase[j] = t_base[r] + seg * 4; ay[j] = t_y[r]; ax[j] = t_x[r];
   }
-  const float* wrow[BR];
-#pragma unroll
-  for (int j = 0; j < BR; ++j) wrow[j] = p.w + (int64_t)(n0 + lrow + 32 * j) * p.w_sn + seg * 4;
 
-  // Gathered operand through a buffer descriptor: an out-of-image tap gets byte offset 0xFFFFFFF0, the hardware range
-  // check returns zeros — no branch and no select, so the loads stay in flight behind the MFMAs (a per-element
-  // `ok ? load : 0` makes hipcc branch around every load and wait vmcnt(0) before the MFMA block).
+  // Both operands are read through buffer descriptors with the K-tile position in the SCALAR offset operand:
+  //   gathered rows : voffset = byte offset of (pixel, tap) — recomputed once per TAP, not per K-tile — or
+  //                   OOB_OFF for an out-of-image tap (the hardware range check returns zeros: no branch, no select);
+  //   filter rows   : voffset fixed for the whole kernel;   soffset = (tap, channel chunk) for both.
+  // On gfx950 the fp32 MFMA runs on the vector ALUs, so every VALU instruction of the address arithmetic is time the
+  // matrix work does not get (stamped build: a wave's load-issue phase is starved for the whole MFMA phase of its SIMD
+  // partner).  Per K-tile this loop now issues 8 loads, 8 LDS writes, 16 LDS reads and ~10 scalar instructions.
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+  uint32_t wvoff[BR];
+#pragma unroll
+  for (int j = 0; j < BR; ++j) wvoff[j] = (uint32_t)(((int64_t)(n0 + lrow + 32 * j) * p.w_sn + seg * 4) * 4);
 
-  u32x4 ra[AR];
-  f32x4 rb[BR];
+  u32x4 ra[AR], rb[BR];
+  uint32_t avoff[AR];
   const int cchunks = p.ld_in / BK;
   const int nk = d.n_taps * cchunks;
   const int h_in = p.h_in, w_in = p.w_in, ld_in = p.ld_in;
+  int w_tap_off = 0;                                    // element offset of the current tap's filter slice
 
-  auto gload = [&](int tap, int c0) {
+  auto set_tap = [&](int tap) {
     const int tp = d.taps[tap];
     const int dy = (int)(int8_t)(tp >> 8), dx = (int)(int8_t)tp;
+    w_tap_off = (tp >> 16) * (int)p.w_st;
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
       const int iy = ay[j] + dy, ix = ax[j] + dx;
       const bool ok = (unsigned)iy < (unsigned)h_in && (unsigned)ix < (unsigned)w_in;
-      const uint32_t off = ok ? (uint32_t)(abase[j] + (iy * w_in + ix) * ld_in + c0) * 4u : 0xFFFFFFF0u;
-      ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+      avoff[j] = ok ? (uint32_t)(abase[j] + (iy * w_in + ix) * ld_in) * 4u : OOB_OFF;
     }
-    const int64_t wo = (int64_t)(tp >> 16) * p.w_st + c0;
+  };
+  auto gload = [&](int c0) {
+    const uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane(c0 * 4);
+    const uint32_t sw = (uint32_t)__builtin_amdgcn_readfirstlane((w_tap_off + c0) * 4);
 #pragma unroll
-    for (int j = 0; j < BR; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + wo);
+    for (int j = 0; j < AR; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, avoff[j], sa, 0);
+#pragma unroll
+    for (int j = 0; j < BR; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wvoff[j], sw, 0);
   };
   auto sstore = [&](int buf) {
     float* a = As + buf * BM * LDT + lrow * LDT + seg * 4;
@@ -150,7 +182,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4*>(a + 32 * j * LDT) = ra[j];
 #pragma unroll
-    for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(b + 32 * j * LDT) = rb[j];
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x4*>(b + 32 * j * LDT) = rb[j];
   };
 
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
@@ -168,17 +200,24 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   // to the other LDS buffer after them (one barrier per K-tile).  (Measured alternative: writing tile it+1 FIRST and
   // prefetching tile it+2 — one tile deeper — is 3-4 % slower here and 5 % faster in wgrad_f32_kernel, which uses it.)
   int tap = 0, c0 = 0, buf = 0;
-  gload(0, 0);
+  set_tap(0);
+  gload(0);
   sstore(0);
   __syncthreads();
 
+#ifdef TG_STAMP
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, acc_load = 0, acc_mfma = 0, acc_store = 0, acc_bar = 0, t_begin = 0;
+  STAMP(t_begin);
+#endif
   for (int it = 0; it < nk; ++it) {
     const bool more = it + 1 < nk;
+    STAMP(ts0);
     if (more) {
       c0 += BK;
-      if (c0 == ld_in) { c0 = 0; ++tap; }
-      gload(tap, c0);
+      if (c0 == ld_in) { c0 = 0; set_tap(++tap); }
+      gload(c0);
     }
+    STAMP(ts1);
     const float* A = As + buf * BM * LDT + wm0 * LDT + frag;
     const float* B = Bs + buf * BN * LDT + wn0 * LDT + frag;
 #pragma unroll
@@ -194,30 +233,87 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][s], a[mi][s], acc[mi][ni], 0, 0, 0);   // D[n][m]: lane = pixel
     }
+    STAMP(ts2);
     if (more) sstore(buf ^ 1);
+    STAMP(ts3);
     __syncthreads();
+    STAMP(ts4);
+#ifdef TG_STAMP
+    acc_load += ts1 - ts0; acc_mfma += ts2 - ts1; acc_store += ts3 - ts2; acc_bar += ts4 - ts3;
+#endif
     buf ^= 1;
   }
+#ifdef TG_STAMP
+  {
+    unsigned long long t_end;
+    STAMP(t_end);
+    const int slot = blockIdx.x == 0 ? 0 : (blockIdx.x == 7 ? 1 : (blockIdx.x == 300 ? 2 : (blockIdx.x == 700 ? 3 : (blockIdx.x == 1500 ? 4 : -1))));
+    if (slot >= 0 && tid == 0) {
+      tg_stamps[slot * 8 + 0] = acc_load; tg_stamps[slot * 8 + 1] = acc_mfma; tg_stamps[slot * 8 + 2] = acc_store;
+      tg_stamps[slot * 8 + 3] = acc_bar; tg_stamps[slot * 8 + 4] = t_end - t_begin; tg_stamps[slot * 8 + 5] = nk;
+      tg_stamps[slot * 8 + 6] = t_begin - t_entry;
+    }
+  }
+  unsigned long long t_epi0 = 0;
+  STAMP(t_epi0);
+#endif
 
-  // epilogue: +bias, activation, masked store (lane = column, 16 rows per 32x32 tile)
+  // epilogue.  The MFMAs were issued with the FILTER as the row operand, so a lane holds ONE output pixel (lane & 31)
+  // and its 16 registers hold channels 8q + 4h + (0..3): four consecutive channels of that pixel are adjacent in NHWC
+  // memory -> 16 dwordx4 stores per lane instead of 64 dword stores (measured: the store tail of a 128x128 tile
+  // drops from ~36k to ~10k cycles).  +bias, activation; masked rows carry an out-of-range byte offset in the row
+  // table, masked channel groups get one here, and the buffer range check drops those stores (no branches).
+  const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
   const int half = lane >> 5, col = lane & 31;
+  const uint32_t* t_ob = reinterpret_cast<const uint32_t*>(t_out);
+  const bool vec_ok = (d.n_store & 3) == 0 && (d.ld_out & 3) == 0;
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wn0 + ni * 32 + col;
-    const bool nok = n < d.n_store;
-    const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+  for (int mi = 0; mi < MI; ++mi) {
+    const uint32_t ro = t_ob[wm0 + mi * 32 + col];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+    for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ml = wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int oo = t_out[ml];
-        if (oo >= 0 && nok) p.out[(int64_t)oo + n] = apply_act(acc[mi][ni][r] + bv, d.act, d.alpha);
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn0 + ni * 32 + 8 * q + 4 * half;
+        float va[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[mi][ni][4 * q + e];
+          if (p.bias != nullptr && n + e < d.n_store) t += p.bias[n + e];
+          va[e] = apply_act(t, d.act, d.alpha);
+        }
+        if (vec_ok) {
+          const uint32_t off = ((ro & OOB_OFF) || n >= d.n_store) ? OOB_OFF : ro + (uint32_t)n * 4u;
+          const u32x4 pk = {__builtin_bit_cast(uint32_t, va[0]), __builtin_bit_cast(uint32_t, va[1]), __builtin_bit_cast(uint32_t, va[2]),
+                            __builtin_bit_cast(uint32_t, va[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_o, off, 0, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t off = ((ro & OOB_OFF) || n + e >= d.n_store) ? OOB_OFF : ro + (uint32_t)(n + e) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, va[e]), rsrc_o, off, 0, 0);
+          }
+        }
       }
     }
   }
+#ifdef TG_STAMP
+  {
+    unsigned long long t_epi1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(t_epi1);
+    const int slot = blockIdx.x == 0 ? 0 : (blockIdx.x == 7 ? 1 : (blockIdx.x == 300 ? 2 : (blockIdx.x == 700 ? 3 : (blockIdx.x == 1500 ? 4 : -1))));
+    if (slot >= 0 && tid == 0) tg_stamps[slot * 8 + 7] = t_epi1 - t_epi0;
+    if (tid == 0 && blockIdx.x < 8192) {
+      tg_block_times[3 * blockIdx.x] = rt0;
+      tg_block_times[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+      tg_block_times[3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                           (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -447,8 +543,22 @@ extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const 
   p.n_img = d->n_img; p.h_in = d->h_in; p.w_in = d->w_in; p.ld_in = d->ld_in; p.c_out = d->c_out;
   p.M = d->n_img * d->h_v * d->w_v;
   const int64_t in_bytes = (int64_t)d->n_img * d->h_in * d->w_in * d->ld_in * 4;
-  TG_REQUIRE(in_bytes < 0xFFFFFFF0LL, "igemm: gathered tensor exceeds the 4 GiB buffer-descriptor range");
+  TG_REQUIRE(in_bytes < 0x7FFFFFF0LL, "igemm: gathered tensor exceeds the 2 GiB buffer-descriptor range");
   p.in_bytes = (uint32_t)in_bytes;
+  int max_tapw = 0;
+  for (int i = 0; i < n_desc; ++i)
+    for (int t = 0; t < descs[i].n_taps; ++t) max_tapw = descs[i].tapw[t] > max_tapw ? descs[i].tapw[t] : max_tapw;
+  const int64_t w_bytes = ((int64_t)(d->c_out - 1) * d->w_sn + (int64_t)max_tapw * d->w_st + d->ld_in) * 4;
+  TG_REQUIRE(w_bytes > 0 && w_bytes < 0x7FFFFFF0LL && d->w_st >= 0 && d->w_sn >= 0 && (int64_t)max_tapw * d->w_st < 0x7FFFFFFFLL,
+             "igemm: filter extent outside the 2 GiB buffer-descriptor range");
+  p.w_bytes = (uint32_t)w_bytes;
+  int64_t out_bytes = 0;
+  for (int i = 0; i < n_desc; ++i) {
+    const int64_t ob = (int64_t)descs[i].n_img * descs[i].h_out * descs[i].w_out * descs[i].ld_out * 4;
+    out_bytes = ob > out_bytes ? ob : out_bytes;
+  }
+  TG_REQUIRE(out_bytes < 0x7FFFFFF0LL, "igemm: output tensor exceeds the 2 GiB buffer-descriptor range");
+  p.out_bytes = (uint32_t)out_bytes;
   double taps = 0;
   for (int i = 0; i < n_desc; ++i) taps += descs[i].n_taps;
   const double flops = 2.0 * p.M * d->c_out * taps * d->ld_in;
@@ -484,6 +594,18 @@ extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const 
   TG_CHECK_LAUNCH("igemm_f32_kernel");
   return TG_OK;
 }
+
+#ifdef TG_STAMP
+extern "C" int tg_debug_read_block_times(unsigned long long* out, int n) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_block_times), sizeof(unsigned long long) * 3 * n);
+  return e == hipSuccess ? 0 : -2;
+}
+
+extern "C" int tg_debug_read_stamps(unsigned long long* out) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_stamps), sizeof(unsigned long long) * 64);
+  return e == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* stream) {
   return tg_igemm_multi_f32(d, 1, in, w, bias, out, stream);
