@@ -95,7 +95,12 @@ class Train(Train_base):
     def _d_forward_backward(self):
         c, cx, m = self.config, self.cx, self.model
         with cx.phase_scope('D', train_nets=('discriminator',)):
-            G = m.good_generator(self.z_g_ph, self.y_g_ph)
+            # The G-update that follows runs the generator on the same feed with the same (not yet updated) weights, and the
+            # generator is deterministic (no dropout / noise): TF recomputes it in the second sess.run, here the forward
+            # pass and its backward closures are kept for _g_forward_backward (bit-identical result, one G forward saved).
+            with cx.sub_tape(('good_generator',)) as g_tape:
+                G = m.good_generator(self.z_g_ph, self.y_g_ph)
+            self._g_saved = (G, g_tape)
             xz = concat_acts([m.as_image(self.x_u_c_ph), m.as_image(self.x_u_d_ph)])
             if m.zca() is not None:
                 xz = m.zca().apply(xz)
@@ -115,11 +120,18 @@ class Train(Train_base):
     def _g_forward_backward(self):
         cx, m = self.cx, self.model
         with cx.phase_scope('G', train_nets=('good_generator',)):
-            G = m.good_generator(self.z_g_ph, self.y_g_ph)
+            saved = getattr(self, '_g_saved', None)
+            if saved is not None:                       # generator forward of the D-update on the same feed and weights
+                G, g_tape = saved
+                self._g_saved = None
+            else:
+                G, g_tape = m.good_generator(self.z_g_ph, self.y_g_ph), None
             with cx.rng_scoped('G/D'):
                 _, d_fake = m.discriminator(G, self.y_g_ph)
             self._g_loss(d_fake, self.loss_dev[1:2])
             cx.backward()
+            if g_tape is not None:
+                cx.run_tape(g_tape)
 
     def _c_forward_backward(self):
         c, cx, m = self.config, self.cx, self.model

@@ -264,6 +264,23 @@ class Context(object):
             self.phase, self.counter, self.tape, self.train_nets = prev
 
     @contextlib.contextmanager
+    def sub_tape(self, train_nets):
+        """record the ops executed inside on a SEPARATE tape (returned) with their own trainable set: lets one solver run
+        keep a forward pass (and its backward closures) for the next run to finish."""
+        prev = (self.tape, self.train_nets)
+        tape = []
+        self.tape, self.train_nets = tape, set(train_nets)
+        try:
+            yield tape
+        finally:
+            self.tape, self.train_nets = prev
+
+    def run_tape(self, tape):
+        for fn in reversed(tape):
+            fn()
+        del tape[:]
+
+    @contextlib.contextmanager
     def variable_scope(self, name):
         self.scopes.append(name)
         try:
