@@ -24,7 +24,10 @@ def init(backend=None):
             local = int(os.environ['TG_DEVICE_INDEX'])
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == 'nccl':
+            kw['device_id'] = torch.device('cuda', local)      # bind the communicator to this rank's GPU up front
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     if 'TG_DEVICE_INDEX' in os.environ:
         local = int(os.environ['TG_DEVICE_INDEX'])
     return world, rank, local

@@ -67,3 +67,23 @@ def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, graph):
     for k in r[0]['p']:
         np.testing.assert_array_equal(r[0]['p'][k], r[1]['p'][k])
     assert r[0]['losses'] != r[1]['losses']                  # ... although each rank trained on its own batch
+
+
+def test_rccl_is_usable_on_this_box(tmp_path):
+    """backend 'nccl' (= RCCL) initialises, all-reduces and tears down on the launch stream the trainer uses (world 1)."""
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='%d')
+torch.cuda.set_device(0)
+s = torch.cuda.Stream(); torch.cuda.set_stream(s)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+t = torch.arange(1 << 20, dtype=torch.float32, device='cuda')
+dist.all_reduce(t); dist.broadcast(t, src=0); dist.barrier()
+m = torch.tensor([2.5], dtype=torch.float64, device='cuda'); dist.all_reduce(m, op=dist.ReduceOp.MAX)
+torch.cuda.synchronize()
+assert float(t[12345]) == 12345.0 and float(m) == 2.5
+dist.destroy_process_group()
+print('rccl ok')
+""" % _free_port()
+    out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert out.returncode == 0 and b'rccl ok' in out.stdout, out.stdout.decode()[-2000:]
