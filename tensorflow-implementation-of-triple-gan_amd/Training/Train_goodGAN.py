@@ -252,7 +252,7 @@ class Train(Train_base):
         cx = self.cx
         with cx.phase_scope('sample', record=False):
             out = self.model.good_sampler(cx.from_numpy(sample_z, key='smp:z'), cx.from_numpy(sample_y, key='smp:y'))
-            return out.numpy()
+            return out.numpy().reshape([-1] + list(self.config.IMAGE_DIM))
 
     # ------------------------------------------------------------------ the reference's entry point
     def train(self, Dataset, Model, sample_y):
@@ -316,3 +316,157 @@ def rampdown(epoch):
         ep = (epoch - (300 - 50)) * 0.5
         return math.exp(-(ep * ep) / 50)
     return 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Experiment entry points (Training/Train_goodGAN.py:472-725).  Same TempConfig attribute values as the reference; the
+# datasets / sample_y files of the reference are not part of its repository, so the synthetic Dataset (same protocol) and a
+# cyclic sample_y are used unless a Dataset class is passed in.  SVHN / CIFAR-10 batch composition: the reference's own
+# pipelines disagree with its placeholders; the consistent protocol is L_C / L_D / U_D+U_C per iteration.
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _root_dir():
+    return os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _customize_config(tmp_config, FLAGS):
+    """:707-720: override config attributes from an argparse-like object."""
+    for k in dir(FLAGS):
+        v = getattr(FLAGS, k)
+        if not k.startswith('_') and not callable(v) and v is not None and hasattr(tmp_config, k.upper()):
+            setattr(tmp_config, k.upper(), v)
+
+
+def _run(TempConfig, Model, Dataset, FLAGS, comments, epochs=None):
+    from Input_Pipeline.syntheticDataset import syntheticDataset
+    tmp_config = TempConfig()
+    if FLAGS:
+        _customize_config(tmp_config, FLAGS)
+    if epochs is not None:
+        tmp_config.EPOCHS = epochs
+    tmp_config.SAMPLE_DIR = os.path.join(_root_dir(), "Training", tmp_config.SAMPLE_DIR)
+    if tmp_config.NUM_LABEL < 1000:
+        tmp_config.PRE_TRAIN = True                                    # :537-538,614-615
+    tmp_config.display()
+    training = Train(tmp_config, tmp_config.LOG_DIR, tmp_config.WEIGHT_DIR, comments=comments + tmp_config.config_str())
+    sample_y = np.eye(tmp_config.NUM_CLASSES, dtype=np.float32)[np.arange(tmp_config.SAMPLE_SIZE) % tmp_config.NUM_CLASSES]
+    return training.train(Dataset or syntheticDataset, Model, sample_y)
+
+
+def _main_training_svhn(FLAGS=None, Dataset=None, epochs=None):
+    """:472-549."""
+    from config import Config
+    from Model.Good_GAN import Good_GAN as Model
+
+    class TempConfig(Config):
+        NAME = "Good_GAN"
+        DATA_NAME = "svhn"
+        DATA_DIR = os.path.join(_root_dir(), "DataSet/svhn")
+        NUM_LABEL = 500
+        BATCH_SIZE = 100
+        BATCH_SIZE_G = BATCH_SIZE
+        BATCH_SIZE_bG = 20
+        BATCH_SIZE_L_C = 50
+        BATCH_SIZE_U_C = 50
+        BATCH_SIZE_L_D = 20
+        BATCH_SIZE_U_D = 80
+        IMAGE_HEIGHT, IMAGE_WIDTH, CHANNEL = 32, 32, 3
+        REPEAT = -1
+        FAKE_G_LAMBDA = 0.03
+        CLA_LEARNINIG_RATE = 3e-4
+        Z_DIM = 100
+        NUM_CLASSES = 10
+        MINIBATCH_DIS = False
+        RESTORE = False
+        LEARNING_RATE = 3e-4
+        EPOCHS = 1000
+        TRAIN_SIZE = 73257 - NUM_LABEL
+        SAVE_PER_EPOCH = 1
+        VAL_STEP = None
+        SAMPLE_DIR = "good_GAN_svhn_500"
+        WEIGHT_DIR = os.path.join(_root_dir(), "Training/Weight_svhn")
+        LOG_DIR = os.path.join(_root_dir(), "Training/Log_svhn")
+
+    return _run(TempConfig, Model, Dataset, FLAGS, "This training is for svhn dataset.", epochs)
+
+
+def _main_training_cifar10(FLAGS=None, Dataset=None, epochs=None):
+    """:551-626.  config.ZCA must carry (mean, mat) when DATA_DIR holds no cifar10_zca_*.npy."""
+    from config import Config
+    from Model.Good_GAN_cifar10 import Good_GAN_cifar10 as Model
+
+    class TempConfig(Config):
+        NAME = "Good_GAN"
+        DATA_NAME = "cifar10"
+        DATA_DIR = os.path.join(_root_dir(), "DataSet/cifar_10")
+        NUM_LABEL = 4000
+        BATCH_SIZE_G = 100
+        BATCH_SIZE_bG = 10
+        BATCH_SIZE_L_C = 50
+        BATCH_SIZE_U_C = 50
+        BATCH_SIZE_L_D = 20
+        BATCH_SIZE_U_D = 80
+        BATCH_SIZE = BATCH_SIZE_G
+        IMAGE_HEIGHT, IMAGE_WIDTH, CHANNEL = 32, 32, 3
+        REPEAT = -1
+        FAKE_G_LAMBDA = 0.3
+        Z_DIM = 100
+        NUM_CLASSES = 10
+        MINIBATCH_DIS = False
+        RESTORE = False                      # the reference resumes a run directory that is not in its repository (:588-592)
+        LEARNING_RATE = 3e-4
+        CLA_LEARNINIG_RATE = 3e-3
+        EPOCHS = 1000
+        TRAIN_SIZE = 60000 - NUM_LABEL
+        SAVE_PER_EPOCH = 1
+        VAL_STEP = None
+        SAMPLE_DIR = "cifar10_good_GAN_4000"
+        WEIGHT_DIR = os.path.join(_root_dir(), "Training/Weight_cifar10")
+        LOG_DIR = os.path.join(_root_dir(), "Training/Log_cifar10")
+
+    if not os.path.exists(os.path.join(TempConfig.DATA_DIR, "cifar10_zca_mat.npy")):
+        q, _ = np.linalg.qr(np.random.default_rng(4321).standard_normal((3072, 3072)))      # SURVEY §8d synthetic whitening
+        TempConfig.ZCA = (np.zeros(3072, np.float32), q.astype(np.float32))
+    return _run(TempConfig, Model, Dataset, FLAGS, "This training is for cifar10 dataset.", epochs)
+
+
+def _main_training_mnist(FLAGS=None, Dataset=None, epochs=None):
+    """:628-705."""
+    from config import Config
+    from Model.Good_GAN import Good_GAN as Model
+
+    class TempConfig(Config):
+        NAME = "Good_GAN"
+        DATA_NAME = "mnist"
+        DATA_DIR = os.path.join(_root_dir(), "DataSet/mnist")
+        NUM_LABEL = 100
+        BATCH_SIZE_G = 100
+        BATCH_SIZE_bG = 100
+        BATCH_SIZE_L_C = 100
+        BATCH_SIZE_U_C = 100
+        BATCH_SIZE_L_D = 20
+        BATCH_SIZE_U_D = 80
+        BATCH_SIZE = BATCH_SIZE_G
+        IMAGE_HEIGHT, IMAGE_WIDTH, CHANNEL = 28, 28, 1
+        REPEAT = -1
+        FAKE_G_LAMBDA = 0.1
+        Z_DIM = 100
+        NUM_CLASSES = 10
+        MINIBATCH_DIS = False
+        RESTORE = False
+        LEARNING_RATE = 1e-3
+        CLA_LEARNINIG_RATE = 3e-4
+        EPOCHS = 1000
+        TRAIN_SIZE = 60000 - NUM_LABEL
+        SAVE_PER_EPOCH = 1
+        VAL_STEP = None
+        SAMPLE_DIR = "mnist_good_GAN_100"
+        WEIGHT_DIR = os.path.join(_root_dir(), "Training/Weight_mnist")
+        LOG_DIR = os.path.join(_root_dir(), "Training/Log_mnist")
+
+    return _run(TempConfig, Model, Dataset, FLAGS, "This training is for mnist dataset.", epochs)
+
+
+if __name__ == "__main__":
+    # :722-725 — the reference launches the MNIST experiment
+    _main_training_mnist()
