@@ -526,10 +526,16 @@ extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const 
   IgemmParams p;
   p.in = in; p.w = w; p.bias = bias; p.out = out; p.n_sub = n_desc;
   const tg_igemm_desc* d = &descs[0];
+  // sub-problems longest first: workgroups are dispatched in index order, so the 9-tap parity of a 5x5 s2 transposed
+  // conv starts before the 4-tap one instead of forming the tail
+  int order[MAX_SUB] = {0, 1, 2, 3};
+  for (int i = 0; i < n_desc; ++i)
+    for (int j = i + 1; j < n_desc; ++j)
+      if (descs[order[j]].n_taps > descs[order[i]].n_taps) { int t_ = order[i]; order[i] = order[j]; order[j] = t_; }
   for (int i = 0; i < n_desc; ++i) {
-    int rc = check_desc(&descs[i]);
+    int rc = check_desc(&descs[order[i]]);
     if (rc != TG_OK) return rc;
-    const tg_igemm_desc& e = descs[i];
+    const tg_igemm_desc& e = descs[order[i]];
     TG_REQUIRE(e.n_img == d->n_img && e.h_v == d->h_v && e.w_v == d->w_v && e.c_out == d->c_out && e.ld_in == d->ld_in && e.h_in == d->h_in &&
                e.w_in == d->w_in && e.w_sn == d->w_sn && e.w_st == d->w_st, "igemm: sub-problem %d differs in M / N / gathered tensor / filter strides", i);
     SubDesc& k = p.d[i];
@@ -573,23 +579,35 @@ extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const 
   // time ~ ceil(tiles / 256 CUs) * tile area / efficiency.  520 tiles of 128x128 cost 3 tile-times per CU, the same
   // problem in 64x64 tiles costs ceil(2080/256) = 9 quarter-size ones.  eff: measured on the classifier layers (N = 250).
   struct Cand { int bm, bn; double eff; };
-  static const Cand cands[] = {{128, 128, 1.00}, {64, 128, 0.97}, {64, 64, 0.96}, {128, 64, 0.95}, {128, 32, 0.70}};
+  static const Cand cands[] = {{128, 128, 1.00}, {64, 128, 0.97}, {64, 64, 0.96}, {128, 64, 0.95}, {32, 128, 0.85}, {128, 32, 0.70}};
   int bm = 128, bn = 32;
   double best = 1e300;
   const char* force = getenv("TG_IGEMM_TILE");     // "bm,bn" — tuning aid
   int fbm = 0, fbn = 0;
   if (force) sscanf(force, "%d,%d", &fbm, &fbn);
+  int max_taps = 0;
+  for (int i = 0; i < n_desc; ++i) max_taps = descs[i].n_taps > max_taps ? descs[i].n_taps : max_taps;
   for (const Cand& c : cands) {
     if (d->c_out % c.bn) continue;
     if (force && (c.bm != fbm || c.bn != fbn)) continue;
-    const int64_t blocks = (int64_t)n_desc * ((p.M + c.bm - 1) / c.bm) * (d->c_out / c.bn);
-    const double t = (double)((blocks + 255) / 256) * c.bm * c.bn / c.eff;
+    const int64_t per_sub = (int64_t)((p.M + c.bm - 1) / c.bm) * (d->c_out / c.bn);
+    // K-tiles per CU: whole rounds for one problem; for the unequal sub-problems of a stride-2 launch (4/6/6/9 taps of a 5x5
+    // transposed conv) the longest workgroup bounds the launch from below, which is what pushes those to small tiles
+    double iters;
+    if (n_desc == 1) {
+      iters = (double)((per_sub + 255) / 256) * max_taps;
+    } else {
+      const double total = (double)per_sub * taps / 256.0;
+      iters = total > max_taps ? total : max_taps;
+    }
+    const double t = iters * c.bm * c.bn / c.eff;
     if (t < best) { best = t; bm = c.bm; bn = c.bn; }
   }
   if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2>(p, s);
   else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2>(p, s);
   else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2>(p, s);
   else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2>(p, s);
+  else if (bm == 32 && bn == 128) launch_igemm<32, 128, 1, 4>(p, s);
   else launch_igemm<128, 32, 4, 1>(p, s);
   TG_CHECK_LAUNCH("igemm_f32_kernel");
   return TG_OK;
