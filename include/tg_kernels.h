@@ -90,6 +90,12 @@ int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const 
 int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,
                        void* stream);
 
+/* tg_igemm_f32 (no bias, no activation) that also accumulates the per-(application segment, channel) sums of its output
+ * into colsum[nseg][c_out] (fp64, zeroed by the call): the tf.nn.moments pass of mean_only_batch_norm_impl
+ * (Model/nn.py:171-175) fused into the convolution.  seg_rows: HOST array, every entry a multiple of 32. */
+int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
+                        double* colsum, void* stream);
+
 /* filter gradient, split over `n_split` pixel ranges:
  * slab[s][t][c][n] = sum_{p in split s} in[pix(p,t),c] * dout[p,n]   (c < ld_in, n < c_out).
  * `dout` is read through (h_out,w_out,ld_out,os,oo) exactly as tg_igemm_f32 writes `out`.
@@ -145,6 +151,11 @@ int tg_seg_actgrad_shift_f32(const float* dy, int ld_dy, const float* yact, int 
  * (1-decay)*mean_s sequentially over s; eval (train = 0): shift[s][k] = b[k] - pop_mean[k]. */
 int tg_mobn_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, int rows, int c, const float* b, float* pop_mean, float decay,
                          int train, float* shift, void* stream);
+/* fused tail of mean-only BN on x (in place): y = act(x - mean_seg + b) with mean_seg = sums[seg]/rows_seg (sums from
+ * tg_igemm_colsum_f32; training: pop_mean <- decay*pop_mean + (1-decay)*mean_seg sequentially over the segments), or
+ * y = act(x - pop_mean + b) when sums is NULL (evaluation).  c <= 512, c % 4 == 0. */
+int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows, int nseg, const double* sums, const float* b, float* pop_mean,
+                      float decay, int act, float alpha, void* stream);
 /* shift[s][k] = -sums[s][k]/rows_s; db[k] = sum_s sums[s][k]. */
 int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, int rows, int c, float* shift, float* db, void* stream);
 /* batch norm (training mode, biased variance) from s1 = sum x and s2 = sum (x-mean)^2 (modes 0 and 4 above):

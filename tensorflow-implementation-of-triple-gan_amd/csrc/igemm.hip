@@ -65,6 +65,8 @@ struct IgemmParams {
   int n_img, h_in, w_in, ld_in, c_out;
   int n_sub, M, m_tiles, n_tiles;
   uint32_t in_bytes, w_bytes, out_bytes;
+  double* colsum;                 // COLSUM variant: [nseg][c_out] fp64 accumulators (zeroed by the launcher)
+  int nseg, seg_rows[8];
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -87,7 +89,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool COLSUM>
 __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
@@ -233,7 +235,8 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][s], a[mi][s], acc[mi][ni], 0, 0, 0);   // D[n][m]: lane = pixel
+            if (COLSUM) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);   // D[m][n]: lane = channel
+            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][s], a[mi][s], acc[mi][ni], 0, 0, 0);        // D[n][m]: lane = pixel
     }
     STAMP(ts2);
     if (more) sstore(buf ^ 1);
@@ -268,6 +271,34 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
   const int half = lane >> 5, col = lane & 31;
   const uint32_t* t_ob = reinterpret_cast<const uint32_t*>(t_out);
+  if (COLSUM) {
+    // Mean-only-BN variant: the pixel operand was the MFMA row operand, so a lane holds ONE output channel and its 16
+    // registers hold rows — the tile's column sum is 16 adds + one cross-half shuffle per lane, accumulated with fp64
+    // atomics into [segment][channel] (masked rows hold exact zeros; tiles never straddle a segment: launcher check).
+    int seg = 0, acc_rows = p.seg_rows[0];
+    while (seg < p.nseg - 1 && m0 >= acc_rows) acc_rows += p.seg_rows[++seg];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn0 + ni * 32 + col;
+      const bool nok = n < d.n_store;
+      const uint32_t ncol = nok ? (uint32_t)n * 4u : OOB_OFF;
+      float csum = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[mi][ni][r];
+          csum += v;
+          const uint32_t ro = t_ob[wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+          const uint32_t off = (ro | ncol) & OOB_OFF ? OOB_OFF : ro + ncol;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rsrc_o, off, 0, 0);
+        }
+      }
+      csum += __shfl_xor(csum, 32, 64);
+      if (half == 0 && nok) atomicAdd(p.colsum + (int64_t)seg * p.c_out + n, (double)csum);
+    }
+    return;
+  }
   const bool vec_ok = (d.n_store & 3) == 0 && (d.ld_out & 3) == 0;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -516,15 +547,18 @@ template <int BM, int BN, int WM_, int WN_>
 static void launch_igemm(IgemmParams& p, hipStream_t s) {
   p.m_tiles = (p.M + BM - 1) / BM;
   p.n_tiles = p.c_out / BN;
-  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_>), dim3(p.m_tiles * p.n_tiles * p.n_sub), dim3(256), 0, s, p);
+  if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true>), dim3(p.m_tiles * p.n_tiles * p.n_sub), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false>), dim3(p.m_tiles * p.n_tiles * p.n_sub), dim3(256), 0, s, p);
 }
 
-extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,
-                                  void* stream) {
+static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out, void* stream,
+                      double* colsum, const int32_t* seg_rows, int nseg) {
   TG_REQUIRE(descs && n_desc >= 1 && n_desc <= MAX_SUB, "igemm: n_desc=%d out of range", n_desc);
   TG_REQUIRE(in && w && out, "igemm: null buffer");
   IgemmParams p;
   p.in = in; p.w = w; p.bias = bias; p.out = out; p.n_sub = n_desc;
+  p.colsum = colsum; p.nseg = nseg;
+  for (int i = 0; i < 8; ++i) p.seg_rows[i] = (seg_rows && i < nseg) ? seg_rows[i] : 0;
   const tg_igemm_desc* d = &descs[0];
   // sub-problems longest first: workgroups are dispatched in index order, so the 9-tap parity of a 5x5 s2 transposed
   // conv starts before the 4-tap one instead of forming the tail
@@ -590,6 +624,9 @@ extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const 
   for (const Cand& c : cands) {
     if (d->c_out % c.bn) continue;
     if (force && (c.bm != fbm || c.bn != fbn)) continue;
+    bool seg_ok = true;                                      // COLSUM: a tile must not straddle two application segments
+    for (int i = 0; colsum && i < nseg; ++i) seg_ok = seg_ok && seg_rows[i] % c.bm == 0;
+    if (!seg_ok) continue;
     const int64_t per_sub = (int64_t)((p.M + c.bm - 1) / c.bm) * (d->c_out / c.bn);
     // K-tiles per CU: whole rounds for one problem; for the unequal sub-problems of a stride-2 launch (4/6/6/9 taps of a 5x5
     // transposed conv) the longest workgroup bounds the launch from below, which is what pushes those to small tiles
@@ -603,6 +640,7 @@ extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const 
     const double t = iters * c.bm * c.bn / c.eff;
     if (t < best) { best = t; bm = c.bm; bn = c.bn; }
   }
+  TG_REQUIRE(best < 1e299, "igemm: no tile fits c_out=%d with the given segments", d->c_out);
   if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2>(p, s);
   else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2>(p, s);
   else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2>(p, s);
@@ -625,8 +663,25 @@ extern "C" int tg_debug_read_stamps(unsigned long long* out) {
 }
 #endif
 
+extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,
+                                  void* stream) {
+  return igemm_impl(descs, n_desc, in, w, bias, out, stream, nullptr, nullptr, 0);
+}
+
 extern "C" int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* stream) {
-  return tg_igemm_multi_f32(d, 1, in, w, bias, out, stream);
+  return igemm_impl(d, 1, in, w, bias, out, stream, nullptr, nullptr, 0);
+}
+
+extern "C" int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
+                                   double* colsum, void* stream) {
+  TG_REQUIRE(d && colsum && seg_rows && nseg >= 1 && nseg <= 8, "igemm_colsum: bad args");
+  TG_REQUIRE(d->act == TG_ACT_NONE, "igemm_colsum: the statistics are of the raw convolution output (no activation)");
+  int tot = 0;
+  for (int i = 0; i < nseg; ++i) { TG_REQUIRE(seg_rows[i] > 0 && seg_rows[i] % 32 == 0, "igemm_colsum: segment %d has %d rows (need a multiple of 32)", i, seg_rows[i]); tot += seg_rows[i]; }
+  TG_REQUIRE(tot == d->n_img * d->h_v * d->w_v, "igemm_colsum: segments sum to %d rows, launch has %d", tot, d->n_img * d->h_v * d->w_v);
+  hipError_t e = hipMemsetAsync(colsum, 0, sizeof(double) * nseg * d->c_out, tg::as_stream(stream));
+  if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(colsum)");
+  return igemm_impl(d, 1, in, w, nullptr, out, stream, colsum, seg_rows, nseg);
 }
 
 template <int CT, int NT, int WC, int WN, int WK>

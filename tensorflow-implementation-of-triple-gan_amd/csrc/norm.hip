@@ -198,6 +198,42 @@ __global__ void __launch_bounds__(256) bn_bwd_apply(const float* __restrict__ dy
   }
 }
 
+// Fused mean-only-BN apply (Model/nn.py:147-187) on the output of tg_igemm_colsum_f32: each workgroup owns 32 consecutive rows
+// (inside one application segment), derives shift[c] = b[c] - sums[seg][c]/rows_seg (training) or b[c] - pop_mean[c]
+// (evaluation) once into LDS, then streams y = act(x + shift) in place with 16-B lanes.  Workgroup 0 also applies the
+// sequential pop_mean updates.  Replaces stage-2 reduction + finalize + apply (three launches, one extra read pass).
+__global__ void __launch_bounds__(256) mobn_apply(float* __restrict__ x, int ld, int rows, int c, SegTable st, const double* __restrict__ sums,
+                                                  const float* __restrict__ b, float* __restrict__ pop, float decay, int act, float alpha) {
+  __shared__ float shift[512];
+  const int r0 = blockIdx.x * 32;
+  int sb;
+  const int seg = seg_of_row(st, r0, &sb);
+  for (int k = threadIdx.x; k < c; k += 256) {
+    const float bb = b ? b[k] : 0.f;
+    shift[k] = sums ? bb - (float)(sums[(int64_t)seg * c + k] / (double)st.rows[seg]) : bb - pop[k];
+  }
+  if (blockIdx.x == 0 && sums) {
+    for (int k = threadIdx.x; k < c; k += 256) {
+      float pm = pop[k];
+      for (int s = 0; s < st.nseg; ++s) pm = pm * decay + (float)(sums[(int64_t)s * c + k] / (double)st.rows[s]) * (1.f - decay);
+      pop[k] = pm;
+    }
+  }
+  __syncthreads();
+  const int c4 = c >> 2;
+  const int rows_here = min(32, rows - r0);
+  for (int i = threadIdx.x; i < rows_here * c4; i += 256) {
+    const int rr = i / c4, cg = i - rr * c4;
+    float4* p = reinterpret_cast<float4*>(x + (int64_t)(r0 + rr) * ld + cg * 4);
+    float4 v = *p;
+    v.x = tgd::act(v.x + shift[cg * 4], act, alpha);
+    v.y = tgd::act(v.y + shift[cg * 4 + 1], act, alpha);
+    v.z = tgd::act(v.z + shift[cg * 4 + 2], act, alpha);
+    v.w = tgd::act(v.w + shift[cg * 4 + 3], act, alpha);
+    *p = v;
+  }
+}
+
 __global__ void mobn_finalize(const float* __restrict__ sums, SegTable st, int c, const float* __restrict__ b, float* __restrict__ pop, float decay,
                               int train, float* __restrict__ shift) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
@@ -388,6 +424,20 @@ int tg_mobn_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, i
   tg::ProfScope prof(tg::PC_NORM, 0, 0, s);
   hipLaunchKernelGGL(mobn_finalize, dim3((c + 127) / 128), dim3(128), 0, s, sums, st, c, b, pop_mean, decay, train, shift);
   TG_CHECK_LAUNCH("mobn_finalize");
+  return TG_OK;
+}
+
+int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows, int nseg, const double* sums, const float* b, float* pop_mean,
+                      float decay, int act, float alpha, void* stream) {
+  SegTable st;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(x && pop_mean && c > 0 && c <= 512 && c % 4 == 0 && ld % 4 == 0 && c <= ld, "mobn_apply: c=%d ld=%d unsupported", c, ld);
+  for (int i = 0; i < nseg; ++i) TG_REQUIRE(seg_rows[i] % 32 == 0 || nseg == 1, "mobn_apply: segment %d has %d rows (need a multiple of 32)", i, seg_rows[i]);
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 8.0 * rows * c, s);
+  hipLaunchKernelGGL(mobn_apply, dim3((rows + 31) / 32), dim3(256), 0, s, x, ld, rows, c, st, sums, b, pop_mean, decay, act, alpha);
+  TG_CHECK_LAUNCH("mobn_apply");
   return TG_OK;
 }
 

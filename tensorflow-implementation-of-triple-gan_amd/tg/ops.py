@@ -87,9 +87,18 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     fused_act = act if mobn is None else None
     d = geom.conv_fwd(x.n, x.h, x.w, ci_p, co_p, k, stride, padding, ld_out=ld_out, n_store=n_store, act=fused_act, alpha=alpha)
     y = cx.new_act(x.n, d.h_out, d.w_out, c_out, ld_out, requires_grad=needs_w or needs_x)
-    _call('tg_igemm_f32', d, x.ptr, _p(w_oti), (_p(bias) if mobn is None else None), y.ptr, cx.stream)
     seg_rows = _segs(y, segments)
-    if mobn is not None:
+    fused = (mobn is not None and train and c_out == co_p and c_out <= 512 and stride == 1 and all(r % 32 == 0 for r in seg_rows))
+    if fused:
+        # convolution + per-(application, channel) sums in one launch, then one fused apply pass (mean, +b, activation, pop_mean)
+        b, b_grad, pop = mobn
+        sums = cx.scratch('cs64', 2 * len(seg_rows) * c_out)          # fp64 accumulators
+        _call('tg_igemm_colsum_f32', d, x.ptr, _p(w_oti), y.ptr, seg_array(seg_rows), len(seg_rows), _p(sums), cx.stream)
+        _call('tg_mobn_apply_f32', y.ptr, y.ld, y.rows, c_out, seg_array(seg_rows), len(seg_rows), _p(sums), _p(b), _p(pop), 0.9, ACT[act],
+              alpha, cx.stream)
+    else:
+        _call('tg_igemm_f32', d, x.ptr, _p(w_oti), (_p(bias) if mobn is None else None), y.ptr, cx.stream)
+    if mobn is not None and not fused:
         b, b_grad, pop = mobn
         sums = None
         if train:
