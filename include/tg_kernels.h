@@ -156,6 +156,11 @@ int tg_mobn_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, i
  * y = act(x - pop_mean + b) when sums is NULL (evaluation).  c <= 512, c % 4 == 0. */
 int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows, int nseg, const double* sums, const float* b, float* pop_mean,
                       float decay, int act, float alpha, void* stream);
+/* fused backward of mean-only BN + nonlinearity: dx = dy*act'(yact) - mean_seg(dy*act'(yact)), db[k] = sum over all rows
+ * (db may be NULL).  sums: scratch of nseg*c doubles.  Two launches (sums with fp64 atomics, apply).  c <= 512, c % 4 == 0,
+ * segment rows multiples of 32. */
+int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
+                    int act, float alpha, double* sums, float* db, void* stream);
 /* shift[s][k] = -sums[s][k]/rows_s; db[k] = sum_s sums[s][k]. */
 int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, int rows, int c, float* shift, float* db, void* stream);
 /* batch norm (training mode, biased variance) from s1 = sum x and s2 = sum (x-mean)^2 (modes 0 and 4 above):

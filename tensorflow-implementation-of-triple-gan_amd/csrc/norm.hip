@@ -234,6 +234,83 @@ __global__ void __launch_bounds__(256) mobn_apply(float* __restrict__ x, int ld,
   }
 }
 
+// Mean-only-BN backward in two launches: (1) sums[seg][c] += sum_rows dy*act'(y) (one fp64 atomic per column per workgroup),
+// (2) dpre = dy*act'(y) - sums[seg]/rows_seg with the shift derived in LDS; workgroup 0 writes db = sum_seg sums.
+__global__ void __launch_bounds__(256) mobn_bwd_sums(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y, int rows, int c,
+                                                     SegTable st, int act, float alpha, double* __restrict__ sums, int units_per_block) {
+  // each workgroup walks units_per_block 32-row units; partial column sums are flushed (one fp64 atomic per column) when the
+  // segment changes and at the end.
+  const int c4 = c >> 2;
+  const int lanes = 256 / c4 > 0 ? 256 / c4 : 1;
+  const int cg = threadIdx.x % c4, rl = threadIdx.x / c4;
+  const int units = (rows + 31) >> 5;
+  const int u0 = blockIdx.x * units_per_block, u1 = min(units, u0 + units_per_block);
+  __shared__ float4 red[256];
+  float4 acc = {0, 0, 0, 0};
+  int cur_seg = -1;
+  for (int u = u0; u <= u1; ++u) {
+    int sb, seg = -2;
+    if (u < u1) seg = seg_of_row(st, u * 32, &sb);
+    if (seg != cur_seg) {
+      if (cur_seg >= 0) {
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (rl == 0) {
+          for (int k = 1; k < lanes; ++k) {
+            const float4 t = red[k * c4 + cg];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+          }
+          double* o = sums + (int64_t)cur_seg * c + cg * 4;
+          atomicAdd(o, (double)acc.x); atomicAdd(o + 1, (double)acc.y); atomicAdd(o + 2, (double)acc.z); atomicAdd(o + 3, (double)acc.w);
+        }
+        __syncthreads();
+        acc = {0, 0, 0, 0};
+      }
+      cur_seg = seg;
+    }
+    if (u < u1 && rl < lanes) {
+      const int r0 = u * 32, rows_here = min(32, rows - r0);
+      for (int rr = rl; rr < rows_here; rr += lanes) {
+        const float4 g = *reinterpret_cast<const float4*>(dy + (int64_t)(r0 + rr) * ld_dy + cg * 4);
+        const float4 yy = *reinterpret_cast<const float4*>(y + (int64_t)(r0 + rr) * ld_y + cg * 4);
+        acc.x += g.x * tgd::act_grad(yy.x, act, alpha); acc.y += g.y * tgd::act_grad(yy.y, act, alpha);
+        acc.z += g.z * tgd::act_grad(yy.z, act, alpha); acc.w += g.w * tgd::act_grad(yy.w, act, alpha);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) mobn_bwd_apply(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
+                                                      float* __restrict__ dx, int ld_dx, int rows, int c, SegTable st, int act, float alpha,
+                                                      const double* __restrict__ sums, float* __restrict__ db) {
+  __shared__ float shift[512];
+  const int r0 = blockIdx.x * 32;
+  int sb;
+  const int seg = seg_of_row(st, r0, &sb);
+  for (int k = threadIdx.x; k < c; k += 256) shift[k] = -(float)(sums[(int64_t)seg * c + k] / (double)st.rows[seg]);
+  if (blockIdx.x == 0 && db) {
+    for (int k = threadIdx.x; k < c; k += 256) {
+      double t = 0.;
+      for (int s = 0; s < st.nseg; ++s) t += sums[(int64_t)s * c + k];
+      db[k] = (float)t;
+    }
+  }
+  __syncthreads();
+  const int c4 = c >> 2;
+  const int rows_here = min(32, rows - r0);
+  for (int i = threadIdx.x; i < rows_here * c4; i += 256) {
+    const int rr = i / c4, cg = i - rr * c4;
+    const float4 g = *reinterpret_cast<const float4*>(dy + (int64_t)(r0 + rr) * ld_dy + cg * 4);
+    const float4 yy = *reinterpret_cast<const float4*>(y + (int64_t)(r0 + rr) * ld_y + cg * 4);
+    float4 o;
+    o.x = g.x * tgd::act_grad(yy.x, act, alpha) + shift[cg * 4];
+    o.y = g.y * tgd::act_grad(yy.y, act, alpha) + shift[cg * 4 + 1];
+    o.z = g.z * tgd::act_grad(yy.z, act, alpha) + shift[cg * 4 + 2];
+    o.w = g.w * tgd::act_grad(yy.w, act, alpha) + shift[cg * 4 + 3];
+    *reinterpret_cast<float4*>(dx + (int64_t)(r0 + rr) * ld_dx + cg * 4) = o;
+  }
+}
+
 __global__ void mobn_finalize(const float* __restrict__ sums, SegTable st, int c, const float* __restrict__ b, float* __restrict__ pop, float decay,
                               int train, float* __restrict__ shift) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
@@ -438,6 +515,28 @@ int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows
   tg::ProfScope prof(tg::PC_NORM, 0, 8.0 * rows * c, s);
   hipLaunchKernelGGL(mobn_apply, dim3((rows + 31) / 32), dim3(256), 0, s, x, ld, rows, c, st, sums, b, pop_mean, decay, act, alpha);
   TG_CHECK_LAUNCH("mobn_apply");
+  return TG_OK;
+}
+
+int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
+                    int act, float alpha, double* sums, float* db, void* stream) {
+  SegTable st;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(dy && yact && dx && sums, "mobn_bwd: null buffer");
+  TG_REQUIRE(c > 0 && c <= 512 && c % 4 == 0 && ld_dy % 4 == 0 && ld_y % 4 == 0 && ld_dx % 4 == 0 && c <= ld_dy && c <= ld_y && c <= ld_dx,
+             "mobn_bwd: c=%d vs ld unsupported", c);
+  for (int i = 0; i < nseg; ++i) TG_REQUIRE(seg_rows[i] % 32 == 0 || nseg == 1, "mobn_bwd: segment %d has %d rows (need a multiple of 32)", i, seg_rows[i]);
+  hipStream_t s = tg::as_stream(stream);
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * nseg * c, s);
+  if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(mobn_bwd sums)");
+  tg::ProfScope prof(tg::PC_NORM, 0, 20.0 * rows * c, s);
+  const int blocks = (rows + 31) / 32;
+  const int upb = (blocks + 767) / 768;
+  hipLaunchKernelGGL(mobn_bwd_sums, dim3((blocks + upb - 1) / upb), dim3(256), 0, s, dy, ld_dy, yact, ld_y, rows, c, st, act, alpha, sums, upb);
+  TG_CHECK_LAUNCH("mobn_bwd_sums");
+  hipLaunchKernelGGL(mobn_bwd_apply, dim3(blocks), dim3(256), 0, s, dy, ld_dy, yact, ld_y, dx, ld_dx, rows, c, st, act, alpha, sums, db);
+  TG_CHECK_LAUNCH("mobn_bwd_apply");
   return TG_OK;
 }
 

@@ -123,6 +123,11 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
             dpre = cx.scratch('dpre', y.rows * co_p)
         if mobn is None and dpre is gy.t:
             pass
+        elif mobn is not None and c_out == co_p and c_out <= 512 and all(r % 32 == 0 for r in seg_rows):
+            db = mobn[1] if needs_w else cx.scratch('db', c_out)
+            sums64 = cx.scratch('bs64', 2 * len(seg_rows) * c_out)
+            _call('tg_mobn_bwd_f32', gy.ptr, gy.ld, y.ptr, y.ld, _p(dpre), co_p, y.rows, c_out, seg_array(seg_rows), len(seg_rows),
+                  ACT[act], alpha, _p(sums64), _p(db), cx.stream)
         elif mobn is not None:
             sums, _ = colstats(2, gy.t, gy.ld, y.t, y.ld, y.rows, c_out, seg_rows, act, alpha)
             sh = cx.scratch('bshift', len(seg_rows) * c_out)
