@@ -32,13 +32,19 @@ def _he_trunc_normal(rng, shape):
     return (x * np.sqrt(1.3 * 2.0 / fan_in)).astype(np.float32)
 
 
-C_CONVS = [('conv1_1', 128, 'SAME'), ('conv1_2', 128, 'SAME'), ('conv1_3', 128, 'SAME'),
-           ('conv2_1', 256, 'SAME'), ('conv2_2', 256, 'SAME'), ('conv2_3', 256, 'SAME'), ('conv3', 512, 'VALID')]
-D_CONVS = [('conv2d_00', 32), ('conv2d_01', 32), ('conv2d_10', 64), ('conv2d_11', 64), ('conv2d_20', 128), ('conv2d_21', 128)]
-G_DECONVS = [('gg_dconv0', 256), ('gg_dconv1', 128), ('gg_dconv2', 3)]
+# layer tables (class attributes so that a deeper variant only lists more rows, Model/Good_GAN_stress64.py)
+C_CONVS = [  # name, filters, padding, max-pool + dropout after       (:106-149)
+    ('conv1_1', 128, 'SAME', False), ('conv1_2', 128, 'SAME', False), ('conv1_3', 128, 'SAME', True),
+    ('conv2_1', 256, 'SAME', False), ('conv2_2', 256, 'SAME', False), ('conv2_3', 256, 'SAME', True), ('conv3', 512, 'VALID', False)]
+D_CONVS = [  # name, filters, stride, dropout after                 (:66-91)
+    ('conv2d_00', 32, 1, False), ('conv2d_01', 32, 2, True), ('conv2d_10', 64, 1, False), ('conv2d_11', 64, 2, True),
+    ('conv2d_20', 128, 1, False), ('conv2d_21', 128, 1, False)]
+G_DECONVS = [('gg_dconv0', 256), ('gg_dconv1', 128), ('gg_dconv2', 3)]      # (:44-57); the last one is the tanh image layer
 
 
 class Good_GAN_cifar10(model_base.NN_Base):
+    C_CONVS, D_CONVS, G_DECONVS = C_CONVS, D_CONVS, G_DECONVS
+
     def __init__(self, config):
         super(Good_GAN_cifar10, self).__init__(config.BATCH_NORM_DECAY, config.BATCH_NORM_EPSILON)
         self.config = config
@@ -46,10 +52,11 @@ class Good_GAN_cifar10(model_base.NN_Base):
         self._zca = None
 
     # ------------------------------------------------------------------ variables
-    @staticmethod
-    def param_specs(z_dim=100, ncls=10):
+    @classmethod
+    def param_specs(cls, z_dim=100, ncls=10):
         """(network, name, shape, trainable, init) in TF creation order."""
         g, d, c = [], [], []
+        C_CONVS, D_CONVS, G_DECONVS = cls.C_CONVS, cls.D_CONVS, cls.G_DECONVS
         p = 'good_generator/'
         g += [(p + 'gg_h0_lin/gg_h0_lin/kernel', (z_dim + ncls, 8192), True, 'he'), (p + 'gg_h0_lin/gg_h0_lin/bias', (8192,), True, 0.)]
         cin = 512
@@ -58,19 +65,19 @@ class Good_GAN_cifar10(model_base.NN_Base):
                 g += [(p + '%s/%s/kernel' % (name, name), (5, 5, cout, cin + ncls), True, 'he'),
                       (p + '%s/%s/bias' % (name, name), (cout,), True, 0.)]
                 cin = cout
-            if i < 3:
+            if i < len(G_DECONVS):
                 bn = p + 'gg_bn%d/' % i
                 g += [(bn + 'beta', (cout,), True, 0.), (bn + 'gamma', (cout,), True, 1.),
                       (bn + 'moving_mean', (cout,), False, 0.), (bn + 'moving_variance', (cout,), False, 1.)]
         cin = 3
-        for name, cout in D_CONVS:
+        for name, cout, _, _ in D_CONVS:
             q = 'discriminator/%s/%s/' % (name, name)
             d += [(q + 'kernel', (3, 3, cin + ncls, cout), True, 'he'), (q + 'bias', (cout,), True, 0.)]
             cin = cout
         d += [('discriminator/lin/lin/kernel', (cin + ncls, 1), True, 'he'), ('discriminator/lin/lin/bias', (1,), True, 0.)]
         cin = 3
-        layers = [('classifier/%s/' % n, (3, 3, cin_, co)) for (n, co, _), cin_ in
-                  zip(C_CONVS, [3] + [co for _, co, _ in C_CONVS[:-1]])]
+        layers = [('classifier/%s/' % n, (3, 3, cin_, co)) for (n, co, _, _), cin_ in
+                  zip(C_CONVS, [3] + [co for _, co, _, _ in C_CONVS[:-1]])]
         layers += [('classifier/NiN1/NiN1/', (512, 256)), ('classifier/NiN2/NiN2/', (256, 128)), ('classifier/output_dense/', (128, ncls))]
         for q, shape in layers:
             c += [(q + 'V', shape, True, 'n05'), (q + 'b', (shape[-1],), True, 0.),
@@ -109,14 +116,15 @@ class Good_GAN_cifar10(model_base.NN_Base):
             zy = ops.cond_concat(z, y.t, y.c)                                        # tf.concat([z, y], 1)
             h0 = self._linear_fc(zy, 4 * 4 * 512, 'gg_h0_lin', activation=self._relu)   # dense + relu (gg_rl0)
             h0 = ops.reshape(self._batch_norm_contrib(_dense_view(h0), 'gg_bn0', train=True), z.n, 4, 4, 512)
-            h0 = self._conv_cond_concat(h0, y)
-            h0 = self._deconv2d(h0, 256, k_w=5, k_h=5, d_w=2, d_h=2, name='gg_dconv0', activation=self._relu)   # [8,8]
-            h0 = self._batch_norm_contrib(h0, 'gg_bn1', train=True)
-            h0 = self._conv_cond_concat(h0, y)
-            h1 = self._deconv2d(h0, 128, k_w=5, k_h=5, d_w=2, d_h=2, name='gg_dconv1', activation=self._relu)   # [16,16]
-            h1 = self._batch_norm_contrib(h1, 'gg_bn2', train=True)
-            h1 = self._conv_cond_concat(h1, y)
-            h2 = self._deconv2d(h1, 3, k_w=5, k_h=5, d_w=2, d_h=2, name='gg_dconv2', activation=self._tanh, narrow=True)
+            h = h0
+            for i, (name, cout) in enumerate(self.G_DECONVS):                        # [8,8], [16,16], [32,32]
+                h = self._conv_cond_concat(h, y)
+                if i + 1 < len(self.G_DECONVS):
+                    h = self._deconv2d(h, cout, k_w=5, k_h=5, d_w=2, d_h=2, name=name, activation=self._relu)
+                    h = self._batch_norm_contrib(h, 'gg_bn%d' % (i + 1), train=True)
+                else:
+                    h = self._deconv2d(h, cout, k_w=5, k_h=5, d_w=2, d_h=2, name=name, activation=self._tanh, narrow=True)
+            h2 = h
         return h2
 
     def good_sampler(self, z, y):
@@ -130,14 +138,11 @@ class Good_GAN_cifar10(model_base.NN_Base):
         lre = self.leakyReLu
         with cx.variable_scope('discriminator'):
             image = self._drop_out(image, 0.2, True)
-            h0 = self._conv2d(self._conv_cond_concat(image, y), 32, k_h=3, k_w=3, d_h=1, d_w=1, name="conv2d_00", activation=lre)
-            h0 = self._conv2d(self._conv_cond_concat(h0, y), 32, k_h=3, k_w=3, d_h=2, d_w=2, name="conv2d_01", activation=lre)
-            h0 = self._drop_out(_dense_view(h0), 0.2, True)                          # [16,16]
-            h1 = self._conv2d(self._conv_cond_concat(h0, y), 64, k_h=3, k_w=3, d_h=1, d_w=1, name="conv2d_10", activation=lre)
-            h1 = self._conv2d(self._conv_cond_concat(h1, y), 64, k_h=3, k_w=3, d_h=2, d_w=2, name="conv2d_11", activation=lre)
-            h1 = self._drop_out(_dense_view(h1), 0.2, True)                          # [8,8]
-            h2 = self._conv2d(self._conv_cond_concat(h1, y), 128, k_h=3, k_w=3, d_h=1, d_w=1, name="conv2d_20", activation=lre)
-            h2 = self._conv2d(self._conv_cond_concat(h2, y), 128, k_h=3, k_w=3, d_h=1, d_w=1, name="conv2d_21", activation=lre)
+            h2 = image
+            for name, cout, stride, drop in self.D_CONVS:
+                h2 = self._conv2d(self._conv_cond_concat(h2, y), cout, k_h=3, k_w=3, d_h=stride, d_w=stride, name=name, activation=lre)
+                if drop:
+                    h2 = self._drop_out(_dense_view(h2), 0.2, True)
             h3 = ops.global_avgpool_concat(h2, y.t, y.c)                             # avg_pool 8 + squeeze + concat y
             h3 = self._linear_fc(h3, 1, 'lin', narrow=True)
         return None, h3
@@ -155,12 +160,12 @@ class Good_GAN_cifar10(model_base.NN_Base):
             # ([3,3,3,128] and [1,1,27,128] are the same bytes)
             noise = cx.rng.normal(cx, 'noise', inp.rows * inp.c, 0.15)
             x = ops.im2col3x3_add(inp, noise)
-            for name, cout, pad in C_CONVS:
-                x = nn.conv2d_WN(x, num_filters=cout, name=name, pad=pad, filter_size=[1, 1] if name == 'conv1_1' else [3, 3], **kw)
-                if name in ('conv1_3', 'conv2_3'):                                   # max_pool_k + dropout_k (:123-124,142-143)
+            for i, (name, cout, pad, pool) in enumerate(self.C_CONVS):
+                x = nn.conv2d_WN(x, num_filters=cout, name=name, pad=pad, filter_size=[1, 1] if i == 0 else [3, 3], **kw)
+                if pool:                                                             # max_pool_k + dropout_k (:123-124,142-143)
                     mask = None
                     if is_training:
-                        mask = cx.rng.keep_mask(cx, 'drop1' if name == 'conv1_3' else 'drop2', x.rows // 4 * x.c, 0.5)
+                        mask = cx.rng.keep_mask(cx, 'drop' + name[4], x.rows // 4 * x.c, 0.5)
                     x = ops.maxpool2_dropout(x, mask, 2.0)
             x = nn.NiN_WN(x, num_units=256, name='NiN1', **kw)
             x = nn.NiN_WN(x, num_units=128, name='NiN2', **kw)

@@ -467,6 +467,43 @@ def _main_training_mnist(FLAGS=None, Dataset=None, epochs=None):
     return _run(TempConfig, Model, Dataset, FLAGS, "This training is for mnist dataset.", epochs)
 
 
+def _main_training_stress64(FLAGS=None, Dataset=None, epochs=None):
+    """Build-defined 64x64x3 / batch-256 stress configuration (not in the reference)."""
+    from config import Config
+    from Model.Good_GAN_stress64 import Good_GAN_stress64 as Model
+
+    class TempConfig(Config):
+        NAME = "Good_GAN"
+        DATA_NAME = "stress64"
+        DATA_DIR = os.path.join(_root_dir(), "DataSet/stress64")
+        NUM_LABEL = 4000
+        BATCH_SIZE_G = 256
+        BATCH_SIZE_bG = 10
+        BATCH_SIZE_L_C = 128
+        BATCH_SIZE_U_C = 128
+        BATCH_SIZE_L_D = 51
+        BATCH_SIZE_U_D = 205
+        BATCH_SIZE = BATCH_SIZE_G
+        IMAGE_HEIGHT, IMAGE_WIDTH, CHANNEL = 64, 64, 3
+        REPEAT = -1
+        FAKE_G_LAMBDA = 0.3
+        Z_DIM = 100
+        NUM_CLASSES = 10
+        MINIBATCH_DIS = False
+        RESTORE = False
+        LEARNING_RATE = 3e-4
+        CLA_LEARNINIG_RATE = 3e-3
+        EPOCHS = 1000
+        TRAIN_SIZE = 60000 - NUM_LABEL
+        SAVE_PER_EPOCH = 1
+        VAL_STEP = None
+        SAMPLE_DIR = "stress64_good_GAN"
+        WEIGHT_DIR = os.path.join(_root_dir(), "Training/Weight_stress64")
+        LOG_DIR = os.path.join(_root_dir(), "Training/Log_stress64")
+
+    return _run(TempConfig, Model, Dataset, FLAGS, "64x64 stress configuration.", epochs)
+
+
 if __name__ == "__main__":
     # :722-725 — the reference launches the MNIST experiment
     _main_training_mnist()
