@@ -103,6 +103,17 @@ int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w,
  * slab holds n_split*n_taps*ld_in*c_out floats; deterministic (no atomics). */
 int tg_wgrad_f32(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream);
 
+/* bf16 MFMA variants of the four launches above (BASELINE.json configs[3], "bf16 MFMA conv path"): identical arguments,
+ * tensors stay fp32 in HBM; every MFMA operand (gathered activation, filter, output gradient) is rounded to bf16
+ * (round-to-nearest-even) inside the kernel and the products accumulate in fp32 (v_mfma_f32_32x32x16_bf16).  Bias,
+ * activation, statistics and the stored result are fp32. */
+int tg_igemm_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* stream);
+int tg_igemm_multi_bf16(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,
+                        void* stream);
+int tg_igemm_colsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
+                         double* colsum, void* stream);
+int tg_wgrad_bf16(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream);
+
 /* ---- parameter-side kernels ---------------------------------------------------------------------- */
 /* scale[c] = g[c] * rsqrt(max(sum_r V[r][c]^2, 1e-12)), V row-major [rows][c].
  * tf.nn.l2_normalize(V,[0,1,2])*g of conv2d_WN (Model/nn.py:502) and g/sqrt(sum V^2) of dense_WN (nn.py:554). */

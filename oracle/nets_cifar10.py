@@ -83,7 +83,7 @@ def classifier_fwd(P, inp, train, rnd, pop_updates=None):
         cache[name + '/x'] = x2
         V, g = P[p + 'V'], P[p + 'g']
         scaler = g / np.sqrt(np.sum(np.square(V), axis=0))  # nn.py:554 (no eps)
-        x2 = (x2 @ V) * scaler
+        x2 = T.matmul(x2, V * scaler) if T.MFMA_BF16 else (x2 @ V) * scaler      # bf16 path: the MFMA sees the effective weight
         x2 = T.lrelu(_wn_mobn(x2, P, p, train, None, pop_updates))
         cache[name + '/y'] = x2
         x = x2.reshape(s[:-1] + (cout,))
@@ -94,7 +94,7 @@ def classifier_fwd(P, inp, train, rnd, pop_updates=None):
     cache['output_dense/x'] = feat
     V, g = P[p + 'V'], P[p + 'g']
     scaler = g / np.sqrt(np.sum(np.square(V), axis=0))
-    logits = _wn_mobn((feat @ V) * scaler, P, p, train, None, pop_updates)
+    logits = _wn_mobn(T.matmul(feat, V * scaler) if T.MFMA_BF16 else (feat @ V) * scaler, P, p, train, None, pop_updates)
     return logits, feat, cache
 
 
@@ -109,10 +109,10 @@ def classifier_bwd(P, cache, dlogits, rnd, dfeat=None):
         dy, db = T.mobn_train_bwd(dy)
         G[p + 'b'] = db
         V, g = P[p + 'V'], P[p + 'g']
-        dW = x2.T @ dy
+        dW = T.matmul(x2.T, dy)
         dv, dg = T.wn_weight_bwd(V, g, dW)
         G[p + 'V'], G[p + 'g'] = dv, dg
-        return dy @ T.wn_weight(V, g).T
+        return T.matmul(dy, T.wn_weight(V, g).T)
 
     dx = dense_wn_bwd('classifier/output_dense/', cache['output_dense/x'], dlogits)
     if dfeat is not None:
@@ -165,7 +165,7 @@ def generator_fwd(P, z, y, eps=1e-5):
     c = {}
     zy = np.concatenate([z, y], axis=1)
     c['zy'] = zy
-    h = zy @ P['good_generator/gg_h0_lin/gg_h0_lin/kernel'] + P['good_generator/gg_h0_lin/gg_h0_lin/bias']
+    h = T.matmul(zy, P['good_generator/gg_h0_lin/gg_h0_lin/kernel']) + P['good_generator/gg_h0_lin/gg_h0_lin/bias']
     h = T.relu(h)
     c['r0'] = h
     h, c['bn0'] = T.batch_norm_train(h, P['good_generator/gg_bn0/gamma'], P['good_generator/gg_bn0/beta'], eps)
@@ -206,7 +206,7 @@ def generator_bwd(P, c, dout):
     G['good_generator/gg_bn0/gamma'], G['good_generator/gg_bn0/beta'] = dg, db
     d = T.relu_bwd_from_out(c['r0'], d)
     G['good_generator/gg_h0_lin/gg_h0_lin/bias'] = d.sum(axis=0)
-    G['good_generator/gg_h0_lin/gg_h0_lin/kernel'] = c['zy'].T @ d
+    G['good_generator/gg_h0_lin/gg_h0_lin/kernel'] = T.matmul(c['zy'].T, d)
     return G
 
 
@@ -245,7 +245,7 @@ def discriminator_fwd(P, image, y, rnd):
     c['pool/shape'] = h.shape
     h = np.concatenate([T.global_avgpool(h), y], axis=1)   # :94-97 avg-pool 8x8 -> [N,128]; concat y
     c['lin/x'] = h
-    logits = h @ P['discriminator/lin/lin/kernel'] + P['discriminator/lin/lin/bias']
+    logits = T.matmul(h, P['discriminator/lin/lin/kernel']) + P['discriminator/lin/lin/bias']
     return logits, c
 
 
@@ -253,8 +253,8 @@ def discriminator_bwd(P, c, dlogits, rnd, want_weight_grads=True, want_input_gra
     G = {}
     if want_weight_grads:
         G['discriminator/lin/lin/bias'] = dlogits.sum(axis=0)
-        G['discriminator/lin/lin/kernel'] = c['lin/x'].T @ dlogits
-    d = (dlogits @ P['discriminator/lin/lin/kernel'].T)[:, :128]
+        G['discriminator/lin/lin/kernel'] = T.matmul(c['lin/x'].T, dlogits)
+    d = T.matmul(dlogits, P['discriminator/lin/lin/kernel'].T)[:, :128]
     d = T.global_avgpool_bwd(d, c['pool/shape'])
     for li in range(len(D_CONVS) - 1, -1, -1):
         name, cout, s, drop = D_CONVS[li]

@@ -179,11 +179,11 @@ def seq_fwd(P, layers, x, y, rnd, train, bn_updates=None):
             x = x.reshape((x.shape[0],) + tuple(l[1]))
         elif k == 'dense':
             c = x
-            x = x @ P[l[1] + '/kernel'] + P[l[1] + '/bias']
+            x = T.matmul(x, P[l[1] + '/kernel']) + P[l[1] + '/bias']
         elif k in ('wn_dense', 'nin'):
             c = (x, x.shape)
             x2 = x.reshape(-1, x.shape[-1])
-            x = (x2 @ _wn_mat(P[l[1] + '/V'], P[l[1] + '/g']) + P[l[1] + '/b']).reshape(x.shape[:-1] + (l[2],))
+            x = (T.matmul(x2, _wn_mat(P[l[1] + '/V'], P[l[1] + '/g'])) + P[l[1] + '/b']).reshape(x.shape[:-1] + (l[2],))
         elif k == 'conv':
             c = x
             x = T.conv2d(x, P[l[1] + '/kernel'], (l[3], l[3]), 'SAME') + P[l[1] + '/bias']
@@ -241,16 +241,16 @@ def seq_bwd(P, layers, caches, d, y, rnd, want_params=True, dfeat=None):
             d = d.reshape(c)
         elif k == 'dense':
             if want_params:
-                G[l[1] + '/kernel'], G[l[1] + '/bias'] = c.T @ d, d.sum(0)
-            d = d @ P[l[1] + '/kernel'].T
+                G[l[1] + '/kernel'], G[l[1] + '/bias'] = T.matmul(c.T, d), d.sum(0)
+            d = T.matmul(d, P[l[1] + '/kernel'].T)
         elif k in ('wn_dense', 'nin'):
             x, shp = c
             x2, d2 = x.reshape(-1, shp[-1]), d.reshape(-1, d.shape[-1])
             V, g = P[l[1] + '/V'], P[l[1] + '/g']
             if want_params:
-                G[l[1] + '/V'], G[l[1] + '/g'] = T.wn_weight_bwd(V, g, x2.T @ d2)
+                G[l[1] + '/V'], G[l[1] + '/g'] = T.wn_weight_bwd(V, g, T.matmul(x2.T, d2))
                 G[l[1] + '/b'] = d2.sum(0)
-            d = (d2 @ _wn_mat(V, g).T).reshape(shp)
+            d = T.matmul(d2, _wn_mat(V, g).T).reshape(shp)
         elif k in ('conv', 'wn_conv'):
             s = (l[3], l[3])
             if k == 'conv':

@@ -52,6 +52,31 @@ def _patches(xp, kh, kw, sh, sw, ho, wo):
 _CHUNK_ELEMS = 48 * 1024 * 1024  # bound the im2col scratch (floats)
 
 
+# --------------------------------------------------------------------------
+# "bf16 MFMA conv path" (BASELINE.json configs[3]) — build-defined, not in the reference: every operand of a
+# conv / transposed-conv / dense contraction (activation, effective filter, output gradient) is rounded to bfloat16
+# (float32 value, round-to-nearest-even on bit 16) and the products are accumulated in the array dtype.  Enabled
+# for a whole step by MFMA_BF16 = True (tests only), or per call through bf16_round().
+# --------------------------------------------------------------------------
+MFMA_BF16 = False
+
+
+def bf16_round(x):
+    x32 = np.ascontiguousarray(x, dtype=np.float32)
+    u = x32.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return r.astype(np.asarray(x).dtype)
+
+
+def _q(x):
+    return bf16_round(x) if MFMA_BF16 else x
+
+
+def matmul(a, b):
+    """a @ b with the operand rounding of the bf16 MFMA path when it is switched on (dense layers of the nets)."""
+    return _q(a) @ _q(b)
+
+
 def _chunks(n, per_image_elems):
     step = max(1, _CHUNK_ELEMS // max(1, per_image_elems))
     for i in range(0, n, step):
@@ -68,8 +93,8 @@ def conv2d(x, w, stride=(1, 1), padding='SAME'):
     assert ci == c
     sh, sw = stride
     ho, wo, pt, pb, pl, pr = _out_and_pad(h, wd, kh, kw, sh, sw, padding)
-    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
-    w2 = w.reshape(kh * kw * ci, co)
+    xp = np.pad(_q(x), ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    w2 = _q(w).reshape(kh * kw * ci, co)
     y = np.empty((n, ho, wo, co), x.dtype)
     for a, b in _chunks(n, ho * wo * kh * kw * c):
         y[a:b] = (_patches(xp[a:b], kh, kw, sh, sw, ho, wo) @ w2).reshape(b - a, ho, wo, co)
@@ -82,7 +107,8 @@ def conv2d_bwd_filter(x, dy, wshape, stride=(1, 1), padding='SAME'):
     sh, sw = stride
     ho, wo, pt, pb, pl, pr = _out_and_pad(h, wd, kh, kw, sh, sw, padding)
     assert dy.shape == (n, ho, wo, co)
-    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    xp = np.pad(_q(x), ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    dy = _q(dy)
     dw = np.zeros((kh * kw * ci, co), x.dtype)
     for a, b in _chunks(n, ho * wo * kh * kw * c):
         dw += _patches(xp[a:b], kh, kw, sh, sw, ho, wo).T @ dy[a:b].reshape(-1, co)
@@ -96,7 +122,8 @@ def conv2d_bwd_input(xshape, w, dy, stride=(1, 1), padding='SAME'):
     ho, wo, pt, pb, pl, pr = _out_and_pad(h, wd, kh, kw, sh, sw, padding)
     assert dy.shape == (n, ho, wo, co), (dy.shape, (n, ho, wo, co))
     dxp = np.zeros((n, h + pt + pb, wd + pl + pr, c), dy.dtype)
-    w2t = w.reshape(kh * kw * ci, co).T
+    dy = _q(dy)
+    w2t = _q(w).reshape(kh * kw * ci, co).T
     for a, b in _chunks(n, ho * wo * kh * kw * c):
         dp = (dy[a:b].reshape(-1, co) @ w2t).reshape(b - a, ho, wo, kh, kw, ci)
         for ky in range(kh):

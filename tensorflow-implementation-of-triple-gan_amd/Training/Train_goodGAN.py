@@ -42,6 +42,11 @@ class Train(Train_base):
         except lib.TgError:
             self.cx = set_context(Context('cuda:%d' % self.local_rank, seed=getattr(config, 'SEED', 0) + 7919 * self.rank))
         cx = self.cx
+        # 'bf16' = BASELINE.json configs[3] "bf16 MFMA conv path": conv / deconv / dense operands rounded to bf16 inside the
+        # MFMA kernels, fp32 accumulation, fp32 tensors, statistics, master weights and optimiser state
+        cx.mfma_dtype = getattr(config, 'MFMA_DTYPE', 'f32')
+        if cx.mfma_dtype not in ('f32', 'bf16'):
+            raise ValueError("MFMA_DTYPE must be 'f32' or 'bf16', got %r" % (cx.mfma_dtype,))
         # device-resident hyper-parameters (the reference's lr_ph / cla_lr_ph / lambda placeholders, :30-31,416-420)
         self.hyper = torch.zeros(4, dtype=torch.float32, device=cx.device)       # lr, cla_lr, lambda_1, lambda_2
         self.loss_dev = torch.zeros(3, dtype=torch.float32, device=cx.device)    # d_loss, g_loss, c_loss

@@ -51,6 +51,7 @@ class Config(object):
     SEED = 0                 # initial weights + Philox stream
     USE_HIP_GRAPH = True     # replay the three solver runs as captured hipGraphs
     ZCA = None               # (mean, mat) arrays when DATA_DIR holds no cifar10_zca_*.npy
+    MFMA_DTYPE = 'f32'       # 'bf16': conv/deconv/dense operands rounded to bf16 inside the MFMA kernels (fp32 accumulate)
 
     def __init__(self):
         """Set values of computed attributes (config.py:70-73)."""

@@ -22,8 +22,20 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
+
+// bf16 variant (tg_*_bf16 entry points): tensors stay fp32 in HBM and in LDS; every MFMA operand fragment is rounded to
+// bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on its way from LDS to the matrix core and the products accumulate in
+// fp32 (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate).  The K permutation is the fp32 kernel's: lane half h supplies
+// k = 16G + 4h + {0..3} and 16G + 8 + 4h + {0..3} of 16-deep group G for both operands.
+__device__ __forceinline__ bf16x8 cvt8(f32x4 lo, f32x4 hi) {
+  bf16x8 r;
+  r[0] = (__bf16)lo[0]; r[1] = (__bf16)lo[1]; r[2] = (__bf16)lo[2]; r[3] = (__bf16)lo[3];
+  r[4] = (__bf16)hi[0]; r[5] = (__bf16)hi[1]; r[6] = (__bf16)hi[2]; r[7] = (__bf16)hi[3];
+  return r;
+}
 
 constexpr int BK = 32;    // reduction depth per LDS tile
 constexpr int LDT = 36;   // padded LDS row stride (floats)
@@ -89,7 +101,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool COLSUM>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool COLSUM, bool BF16>
 __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
@@ -222,6 +234,24 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     STAMP(ts1);
     const float* A = As + buf * BM * LDT + wm0 * LDT + frag;
     const float* B = Bs + buf * BN * LDT + wn0 * LDT + frag;
+    if constexpr (BF16) {
+#pragma unroll
+      for (int G = 0; G < BK / 16; ++G) {
+        bf16x8 a[MI], b[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          a[mi] = cvt8(*reinterpret_cast<const f32x4*>(A + mi * 32 * LDT + G * 16), *reinterpret_cast<const f32x4*>(A + mi * 32 * LDT + G * 16 + 8));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          b[ni] = cvt8(*reinterpret_cast<const f32x4*>(B + ni * 32 * LDT + G * 16), *reinterpret_cast<const f32x4*>(B + ni * 32 * LDT + G * 16 + 8));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            if (COLSUM) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       f32x4 a[MI], b[NI];
@@ -237,6 +267,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
           for (int ni = 0; ni < NI; ++ni)
             if (COLSUM) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);   // D[m][n]: lane = channel
             else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][s], a[mi][s], acc[mi][ni], 0, 0, 0);        // D[n][m]: lane = pixel
+    }
     }
     STAMP(ts2);
     if (more) sstore(buf ^ 1);
@@ -363,7 +394,7 @@ struct WgradParams {
 
 constexpr uint32_t WG_INVALID = 0x80000000u;   // byte offset beyond any (< 2 GiB) operand: the buffer range check yields zeros
 
-template <int CT, int NT, int WAVES_C, int WAVES_N, int WAVES_K>
+template <int CT, int NT, int WAVES_C, int WAVES_N, int WAVES_K, bool BF16>
 __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
   static_assert(WAVES_C * WAVES_N * WAVES_K == 4, "4 waves");
   constexpr int WC = CT / WAVES_C, WN = NT / WAVES_N, MI = WC / 32, NI = WN / 32;
@@ -468,6 +499,28 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
     if (tid < BK && it + 3 < nk) fill_tbl(it + 3);
     const float* A = smem + buf * TILE + (16 * half) * CT + wc0 + col;
     const float* B = smem + buf * TILE + BK * CT + (16 * half) * NT + wn0 + col;
+    if constexpr (BF16) {
+      // lane half h supplies pixels 16G + 8h + {0..7} of 16-pixel group G (eight conflict-free ds_read_b32 per fragment)
+      const float* Ab = smem + buf * TILE + (8 * half) * CT + wc0 + col;
+      const float* Bb = smem + buf * TILE + BK * CT + (8 * half) * NT + wn0 + col;
+#pragma unroll
+      for (int G = wk; G < BK / 16; G += WAVES_K) {
+        bf16x8 a[MI], bv[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[mi][j] = (__bf16)Ab[(16 * G + j) * CT + mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bv[ni][j] = (__bf16)Bb[(16 * G + j) * NT + ni * 32];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int s = wk; s < 16; s += WAVES_K) {
       float a[MI], bv[NI];
@@ -480,6 +533,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+    }
     }
     __syncthreads();
     buf ^= 1;
@@ -544,15 +598,21 @@ int check_desc(const tg_igemm_desc* d) {
 }  // namespace
 
 template <int BM, int BN, int WM_, int WN_>
-static void launch_igemm(IgemmParams& p, hipStream_t s) {
+static void launch_igemm(IgemmParams& p, hipStream_t s, bool bf16) {
   p.m_tiles = (p.M + BM - 1) / BM;
   p.n_tiles = p.c_out / BN;
-  if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true>), dim3(p.m_tiles * p.n_tiles * p.n_sub), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false>), dim3(p.m_tiles * p.n_tiles * p.n_sub), dim3(256), 0, s, p);
+  const dim3 grid(p.m_tiles * p.n_tiles * p.n_sub);
+  if (bf16) {
+    if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, true>), grid, dim3(256), 0, s, p);
+  } else {
+    if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, false>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, false>), grid, dim3(256), 0, s, p);
+  }
 }
 
 static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out, void* stream,
-                      double* colsum, const int32_t* seg_rows, int nseg) {
+                      double* colsum, const int32_t* seg_rows, int nseg, bool bf16 = false) {
   TG_REQUIRE(descs && n_desc >= 1 && n_desc <= MAX_SUB, "igemm: n_desc=%d out of range", n_desc);
   TG_REQUIRE(in && w && out, "igemm: null buffer");
   IgemmParams p;
@@ -604,7 +664,8 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
   const double flops = 2.0 * p.M * d->c_out * taps * d->ld_in;
   const double bytes = 4.0 * ((double)p.M * d->ld_in + (double)p.M * d->n_store * n_desc + (double)d->c_out * taps * d->ld_in);
   char desc[96];
-  snprintf(desc, sizeof(desc), "M=%dx%d N=%d K=%gx%d in=%dx%d s=%d os=%d", n_desc, p.M, d->c_out, taps, d->ld_in, d->h_in, d->w_in, d->s_y, d->os_y);
+  snprintf(desc, sizeof(desc), "M=%dx%d N=%d K=%gx%d in=%dx%d s=%d os=%d%s", n_desc, p.M, d->c_out, taps, d->ld_in, d->h_in, d->w_in, d->s_y, d->os_y,
+           bf16 ? " bf16" : "");
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_IGEMM, flops, bytes, s, desc);
   // tile choice: the largest tile that still gives >= ~1.5 workgroups per CU (2 are resident); small problems (generator,
@@ -641,12 +702,12 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
     if (t < best) { best = t; bm = c.bm; bn = c.bn; }
   }
   TG_REQUIRE(best < 1e299, "igemm: no tile fits c_out=%d with the given segments", d->c_out);
-  if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2>(p, s);
-  else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2>(p, s);
-  else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2>(p, s);
-  else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2>(p, s);
-  else if (bm == 32 && bn == 128) launch_igemm<32, 128, 1, 4>(p, s);
-  else launch_igemm<128, 32, 4, 1>(p, s);
+  if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2>(p, s, bf16);
+  else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2>(p, s, bf16);
+  else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2>(p, s, bf16);
+  else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2>(p, s, bf16);
+  else if (bm == 32 && bn == 128) launch_igemm<32, 128, 1, 4>(p, s, bf16);
+  else launch_igemm<128, 32, 4, 1>(p, s, bf16);
   TG_CHECK_LAUNCH("igemm_f32_kernel");
   return TG_OK;
 }
@@ -672,8 +733,8 @@ extern "C" int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float
   return igemm_impl(d, 1, in, w, bias, out, stream, nullptr, nullptr, 0);
 }
 
-extern "C" int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
-                                   double* colsum, void* stream) {
+static int igemm_colsum_impl(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
+                             double* colsum, void* stream, bool bf16) {
   TG_REQUIRE(d && colsum && seg_rows && nseg >= 1 && nseg <= 8, "igemm_colsum: bad args");
   TG_REQUIRE(d->act == TG_ACT_NONE, "igemm_colsum: the statistics are of the raw convolution output (no activation)");
   int tot = 0;
@@ -681,18 +742,38 @@ extern "C" int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, cons
   TG_REQUIRE(tot == d->n_img * d->h_v * d->w_v, "igemm_colsum: segments sum to %d rows, launch has %d", tot, d->n_img * d->h_v * d->w_v);
   hipError_t e = hipMemsetAsync(colsum, 0, sizeof(double) * nseg * d->c_out, tg::as_stream(stream));
   if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(colsum)");
-  return igemm_impl(d, 1, in, w, nullptr, out, stream, colsum, seg_rows, nseg);
+  return igemm_impl(d, 1, in, w, nullptr, out, stream, colsum, seg_rows, nseg, bf16);
+}
+
+extern "C" int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
+                                   double* colsum, void* stream) {
+  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, stream, false);
+}
+
+extern "C" int tg_igemm_colsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
+                                    double* colsum, void* stream) {
+  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, stream, true);
+}
+
+extern "C" int tg_igemm_multi_bf16(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,
+                                   void* stream) {
+  return igemm_impl(descs, n_desc, in, w, bias, out, stream, nullptr, nullptr, 0, true);
+}
+
+extern "C" int tg_igemm_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* stream) {
+  return igemm_impl(d, 1, in, w, bias, out, stream, nullptr, nullptr, 0, true);
 }
 
 template <int CT, int NT, int WC, int WN, int WK>
-static void launch_wgrad(WgradParams& p, hipStream_t s) {
+static void launch_wgrad(WgradParams& p, hipStream_t s, bool bf16) {
   p.c_tiles = p.d.ld_in / CT;
   p.n_tiles = p.d.c_out / NT;
   int blocks = p.n_split * p.d.n_taps * p.c_tiles * p.n_tiles;
-  hipLaunchKernelGGL((wgrad_f32_kernel<CT, NT, WC, WN, WK>), dim3(blocks), dim3(256), 0, s, p);
+  if (bf16) hipLaunchKernelGGL((wgrad_f32_kernel<CT, NT, WC, WN, WK, true>), dim3(blocks), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((wgrad_f32_kernel<CT, NT, WC, WN, WK, false>), dim3(blocks), dim3(256), 0, s, p);
 }
 
-extern "C" int tg_wgrad_f32(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream) {
+static int wgrad_impl(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream, bool bf16) {
   int rc = check_desc(d);
   if (rc != TG_OK) return rc;
   TG_REQUIRE(in && dout && slab, "wgrad: null buffer");
@@ -707,20 +788,29 @@ extern "C" int tg_wgrad_f32(const tg_igemm_desc* d, const float* in, const float
   const double flops = 2.0 * p.M * d->c_out * d->n_taps * d->ld_in;
   const double bytes = 4.0 * ((double)p.M * d->ld_in + (double)p.M * d->c_out + (double)n_split * d->c_out * d->n_taps * d->ld_in);
   char desc[96];
-  snprintf(desc, sizeof(desc), "M=%d N=%d K=%dx%d in=%dx%d s=%d split=%d", p.M, d->c_out, d->n_taps, d->ld_in, d->h_in, d->w_in, d->s_y, n_split);
+  snprintf(desc, sizeof(desc), "M=%d N=%d K=%dx%d in=%dx%d s=%d split=%d%s", p.M, d->c_out, d->n_taps, d->ld_in, d->h_in, d->w_in, d->s_y, n_split,
+           bf16 ? " bf16" : "");
   tg::ProfScope prof(tg::PC_WGRAD, flops, bytes, tg::as_stream(stream), desc);
   hipStream_t s = tg::as_stream(stream);
   const int ct = d->ld_in % 128 == 0 ? 128 : (d->ld_in % 64 == 0 ? 64 : 32);
   const int nt = d->c_out % 128 == 0 ? 128 : (d->c_out % 64 == 0 ? 64 : 32);
-  if (ct == 128 && nt == 128) launch_wgrad<128, 128, 2, 2, 1>(p, s);
-  else if (ct == 128 && nt == 64) launch_wgrad<128, 64, 2, 2, 1>(p, s);
-  else if (ct == 128 && nt == 32) launch_wgrad<128, 32, 4, 1, 1>(p, s);
-  else if (ct == 64 && nt == 128) launch_wgrad<64, 128, 2, 2, 1>(p, s);
-  else if (ct == 64 && nt == 64) launch_wgrad<64, 64, 2, 2, 1>(p, s);
-  else if (ct == 64 && nt == 32) launch_wgrad<64, 32, 2, 1, 2>(p, s);
-  else if (ct == 32 && nt == 128) launch_wgrad<32, 128, 1, 4, 1>(p, s);
-  else if (ct == 32 && nt == 64) launch_wgrad<32, 64, 1, 2, 2>(p, s);
-  else launch_wgrad<32, 32, 1, 1, 4>(p, s);
+  if (ct == 128 && nt == 128) launch_wgrad<128, 128, 2, 2, 1>(p, s, bf16);
+  else if (ct == 128 && nt == 64) launch_wgrad<128, 64, 2, 2, 1>(p, s, bf16);
+  else if (ct == 128 && nt == 32) launch_wgrad<128, 32, 4, 1, 1>(p, s, bf16);
+  else if (ct == 64 && nt == 128) launch_wgrad<64, 128, 2, 2, 1>(p, s, bf16);
+  else if (ct == 64 && nt == 64) launch_wgrad<64, 64, 2, 2, 1>(p, s, bf16);
+  else if (ct == 64 && nt == 32) launch_wgrad<64, 32, 2, 1, 2>(p, s, bf16);
+  else if (ct == 32 && nt == 128) launch_wgrad<32, 128, 1, 4, 1>(p, s, bf16);
+  else if (ct == 32 && nt == 64) launch_wgrad<32, 64, 1, 2, 2>(p, s, bf16);
+  else launch_wgrad<32, 32, 1, 1, 4>(p, s, bf16);
   TG_CHECK_LAUNCH("wgrad_f32_kernel");
   return TG_OK;
+}
+
+extern "C" int tg_wgrad_f32(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream) {
+  return wgrad_impl(d, in, dout, slab, n_split, stream, false);
+}
+
+extern "C" int tg_wgrad_bf16(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream) {
+  return wgrad_impl(d, in, dout, slab, n_split, stream, true);
 }

@@ -8,7 +8,15 @@ from . import geom, lib
 from .lib import ACT
 from .runtime import Act, ctx, pad32, seg_array
 
-_call = lib.call
+_MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_wgrad_f32')
+
+
+def _call(name, *args):
+    """lib.call; the four MFMA launches switch to their bf16-operand variants when the context asks for the
+    "bf16 MFMA conv path" (Context.mfma_dtype = 'bf16', BASELINE.json configs[3])."""
+    if name in _MFMA_F32 and ctx().mfma_dtype == 'bf16':
+        name = name[:-3] + 'bf16'
+    return lib.call(name, *args)
 
 
 def _p(t):
@@ -38,6 +46,14 @@ def colstats(mode, a_t, ld_a, b_t, ld_b, rows, c, seg_rows, act=None, alpha=0.2,
     _call('tg_colstats_f32', mode, _p(a_t), ld_a, _p(b_t), ld_b, rows, c, seg_array(seg_rows), nseg, ACT[act], alpha,
           _p(work), _p(s1), _p(s2), cx.stream)
     return s1, s2
+
+
+_IGEMM_TILES = ((128, 128), (64, 128), (64, 64), (128, 64), (32, 128), (128, 32))     # csrc/igemm.hip igemm_impl candidates
+
+
+def _colsum_tile_exists(c_out, seg_rows):
+    """tg_igemm_colsum_* needs a tile whose rows never straddle two application segments (and at most 8 segments)."""
+    return len(seg_rows) <= 8 and any(c_out % bn == 0 and all(r % bm == 0 for r in seg_rows) for bm, bn in _IGEMM_TILES)
 
 
 def wgrad_splits(desc, m):
@@ -88,7 +104,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     d = geom.conv_fwd(x.n, x.h, x.w, ci_p, co_p, k, stride, padding, ld_out=ld_out, n_store=n_store, act=fused_act, alpha=alpha)
     y = cx.new_act(x.n, d.h_out, d.w_out, c_out, ld_out, requires_grad=needs_w or needs_x)
     seg_rows = _segs(y, segments)
-    fused = (mobn is not None and train and c_out == co_p and c_out <= 512 and stride == 1 and all(r % 32 == 0 for r in seg_rows))
+    fused = (mobn is not None and train and c_out == co_p and c_out <= 512 and stride == 1 and _colsum_tile_exists(c_out, seg_rows))
     if fused:
         # convolution + per-(application, channel) sums in one launch, then one fused apply pass (mean, +b, activation, pop_mean)
         b, b_grad, pop = mobn

@@ -199,6 +199,7 @@ class Context(object):
         self.rng = PhiloxRNG(seed, self.device)
         self.train_nets = set()
         self._stream = None
+        self.mfma_dtype = 'f32'          # 'bf16': MFMA operands rounded to bf16 inside the kernels (tensors stay fp32)
 
     # ---- streams ---------------------------------------------------------------------------------
     @property

@@ -11,7 +11,7 @@ import gpu_common as G
 from test_oracle_goodgan import scrambled
 
 pytestmark = pytest.mark.gpu
-ACT_TOL, GRAD_L2, GRAD_MAX = 2e-4, 1e-2, 5e-2
+TOL = {'f32': dict(act=2e-4, l2=1e-2, mx=5e-2, loss=5e-4, stat=1e-3), 'bf16': dict(act=3e-2, l2=0.35, mx=0.6, loss=2e-2, stat=2e-2)}
 NETS = {'D': 'discriminator', 'G': 'good_generator', 'C': 'classifier'}
 SMALL = dict(B_G=6, L_C=4, U_C=4, L_D=2, U_D=4)
 
@@ -20,25 +20,61 @@ def f64(d):
     return {k: (f64(v) if isinstance(v, dict) else np.asarray(v, np.float64)) for k, v in d.items()}
 
 
-def trainer(data, P, sizes=SMALL):
+def trainer(data, P, sizes=SMALL, prec='f32'):
     from Model.Good_GAN import Good_GAN
-    return G.fresh_trainer(G.make_config_goodgan(data, sizes), {k: v.astype(np.float32) for k, v in P.items()}, Good_GAN)
+    return G.fresh_trainer(G.make_config_goodgan(data, sizes, MFMA_DTYPE=prec), {k: v.astype(np.float32) for k, v in P.items()}, Good_GAN)
 
 
-def check_grads(store, gref, gmax_floor=1e-4):
+# ('svhn', 'bf16') = BASELINE.json configs[3]: the MFMA launches round their operands to bfloat16 (tg_*_bf16); the oracle
+# emulates exactly that rounding (oracle/tf_ops.py MFMA_BF16) on its float64 arithmetic.  The rounding step turns fp32
+# accumulation noise into bf16-sized noise: an activation that differs by 1e-6..1e-5 (relative) between the two sides
+# lands on the other side of a bf16 rounding boundary with probability (that difference)/2^-8 ~ 0.1 %, and every such
+# operand then differs by 2^-8.  The size of that effect is measured WITHOUT the GPU in
+# tests/test_oracle_goodgan.py::test_bf16_rounding_amplifies_accumulation_noise (the oracle in float32 against the oracle
+# in float64, same rounding rule: generator output 2e-3, generator gradients 2.4e-3, classifier logits 8e-3..1e-2,
+# classifier gradients 7-9 % in aggregate and up to 24 % for single small parameters behind its ten batch norms, against
+# 5e-6 without the rounding) and sets the bf16 tolerances below (1.5-3x that floor: an integration check); the op-level tests (tests/test_gpu_igemm.py, the same rounded
+# operands on both sides) hold the fp32 tolerance.
+CASES = [('mnist', 'f32'), ('svhn', 'f32'), ('svhn', 'bf16')]
+
+
+@pytest.fixture
+def oracle_prec():
+    from oracle import tf_ops as T
+
+    def set_(prec):
+        T.MFMA_BF16 = prec == 'bf16'
+    yield set_
+    T.MFMA_BF16 = False
+
+
+# gradients that are analytically ZERO (a shift in front of a batch norm with only linear maps in between: the batch-norm
+# input gradient sums to zero over the batch).  In fp32 what is left is 1e-7 noise under the floor below; with bf16 operands
+# the residue is sum_n round_bf16(dx_n) @ W — pure rounding residue of both sides, compared by magnitude only.
+ANALYTIC_ZERO = ('classifier/c_h2_bn2/beta', 'classifier/c_h2_lin/c_h2_lin/bias')     # found with the exact float64 oracle: |g| < 1e-9 max|g|
+
+
+def check_grads(store, gref, gmax_floor=1e-4, tol=TOL['f32']):
+    GRAD_MAX, GRAD_L2 = tol['mx'], tol['l2']
     gmax = max(np.abs(v).max() for v in gref.values())
     for k, ref in gref.items():
+        if tol is TOL['bf16'] and k in ANALYTIC_ZERO:
+            assert np.abs(store.get(k, 'grad')).max() <= 2e-2 * gmax, ('analytic zero', k)
+            continue
         d = store.get(k, 'grad') - ref
         sc = max(np.abs(ref).max(), gmax_floor * gmax)        # biases in front of a batch norm have analytically zero gradients: fp32 noise
         assert np.abs(d).max() <= GRAD_MAX * sc, ('max', k, np.abs(d).max(), sc)
         assert np.linalg.norm(d) <= GRAD_L2 * max(np.linalg.norm(ref), sc), ('L2', k)
 
 
-@pytest.mark.parametrize("data", ['mnist', 'svhn'])
-def test_networks_forward_backward(data):
+@pytest.mark.parametrize("data,prec", CASES)
+def test_networks_forward_backward(data, prec, oracle_prec):
     from tg.runtime import InjectedRNG
+    oracle_prec(prec)
+    tol = TOL[prec]
+    ACT_TOL, GRAD_MAX = tol['act'], tol['mx']
     P = {k: v.astype(np.float32).astype(np.float64) for k, v in scrambled(data, 3).items()}
-    tr = trainer(data, P)
+    tr = trainer(data, P, prec=prec)
     cx, m = tr.cx, tr.model
     n = 5
     sizes = dict(B_G=n, L_C=n, U_C=n, L_D=1, U_D=n - 1)
@@ -54,7 +90,7 @@ def test_networks_forward_backward(data):
         o.grad = cx.from_numpy(do.reshape(o.numpy().shape))
         cx.backward()
     assert G.rel_err(o.numpy().reshape(out.shape), out) < ACT_TOL
-    check_grads(cx.stores['good_generator'], gref)
+    check_grads(cx.stores['good_generator'], gref, tol=tol)
     # ---- discriminator (weights and input gradient)
     r = rnd['G']['D_fake']
     img = b['x_l_c']
@@ -70,7 +106,7 @@ def test_networks_forward_backward(data):
         lg.grad = cx.from_numpy(dl, ld=32)
         cx.backward()
     assert G.rel_err(lg.numpy(), logits) < ACT_TOL
-    check_grads(cx.stores['discriminator'], gref)
+    check_grads(cx.stores['discriminator'], gref, tol=tol)
     assert G.rel_err(ia.grad.numpy().reshape(dimg.shape), dimg) < GRAD_MAX
     # ---- classifier: training mode (gradients, moving statistics) and evaluation mode
     r = rnd['C']['C_real']
@@ -86,7 +122,7 @@ def test_networks_forward_backward(data):
         lg.grad = cx.from_numpy(dl, ld=32)
         cx.backward()
     assert G.rel_err(lg.numpy(), logits) < ACT_TOL and G.rel_err(fm.numpy(), feat) < ACT_TOL
-    check_grads(cx.stores['classifier'], gref)
+    check_grads(cx.stores['classifier'], gref, tol=tol)
     st = cx.stores['classifier']
     for name, (mm, mv) in bnu.items():
         assert G.rel_err(st.get(name + '/moving_mean'), mm) < ACT_TOL, name
@@ -100,12 +136,15 @@ def test_networks_forward_backward(data):
     assert G.rel_err(lge.numpy(), le) < ACT_TOL
 
 
-@pytest.mark.parametrize("data", ['mnist', 'svhn'])
-def test_synchronised_iteration(data):
+@pytest.mark.parametrize("data,prec", CASES)
+def test_synchronised_iteration(data, prec, oracle_prec):
     from tg.runtime import InjectedRNG
+    oracle_prec(prec)
+    tol = TOL[prec]
+    ACT_TOL, GRAD_MAX = tol['act'], tol['mx']
     P32 = {k: v.astype(np.float32) for k, v in scrambled(data, 11).items()}
     st = S.new_state(f64(P32))
-    tr = trainer(data, f64(P32))
+    tr = trainer(data, f64(P32), prec=prec)
     hyper = dict(lr=1e-3, cla_lr=3e-4, beta1=0.5, lambda_1=0.1, lambda_2=0.0)
     tr.set_hyper(hyper['lr'], hyper['cla_lr'], hyper['lambda_1'], 0.0)
     cx, stores = tr.cx, tr.cx.stores
@@ -120,22 +159,22 @@ def test_synchronised_iteration(data):
 
     d_ref = S.d_phase(st, data, b64, r64['D'], hyper)
     tr._d_forward_backward()
-    check_grads(stores['discriminator'], st['last_grads']['D'])
+    check_grads(stores['discriminator'], st['last_grads']['D'], tol=tol)
     tr._train_op(tr.d_optimizer, stores['discriminator'])
     for net in NETS.values():
         sync(net)                                  # includes the classifier / generator moving statistics
     g_ref = S.g_phase(st, data, b64, r64['G'], hyper)
     tr._g_forward_backward()
-    check_grads(stores['good_generator'], st['last_grads']['G'])
+    check_grads(stores['good_generator'], st['last_grads']['G'], tol=tol)
     tr._train_op(tr.g_optimizer, stores['good_generator'])
     for net in NETS.values():
         sync(net)
     c_ref = S.c_phase(st, data, b64, r64['C'], hyper)
     tr._c_forward_backward()
-    check_grads(stores['classifier'], st['last_grads']['C'])
+    check_grads(stores['classifier'], st['last_grads']['C'], tol=tol)
     tr._c_apply()
     for r, g in zip((d_ref, g_ref, c_ref), tr.losses()):
-        assert abs(r - g) <= 5e-4 * max(1.0, abs(r)), ((d_ref, g_ref, c_ref), tr.losses())
+        assert abs(r - g) <= tol['loss'] * max(1.0, abs(r)), ((d_ref, g_ref, c_ref), tr.losses())
     cs = stores['classifier']
     for k in cs.names(False):                      # classifier moving statistics after its three training applications
-        assert G.rel_err(cs.get(k), st['P'][k]) < 1e-3, k
+        assert G.rel_err(cs.get(k), st['P'][k]) < tol['stat'], k

@@ -31,6 +31,16 @@ def close(a, b, scale):
     assert err <= 3e-5 * scale, (err, scale)
 
 
+# 'bf16': the tg_*_bf16 variants (operands rounded to bfloat16 inside the kernel, fp32 accumulation) against the oracle
+# run on operands rounded the same way (T.bf16_round) — the products are then exact in fp32 and the tolerance is the
+# fp32 accumulation-order bound of the f32 case.
+PRECS = ['f32', 'bf16']
+
+
+def _q(prec, x):
+    return T.bf16_round(x) if prec == 'bf16' else x
+
+
 CONV_CASES = [  # n,h,w,cin,cout,k,stride,pad
     (3, 8, 8, 32, 32, 3, 1, 'SAME'),
     (5, 16, 16, 64, 128, 3, 1, 'SAME'),
@@ -42,15 +52,17 @@ CONV_CASES = [  # n,h,w,cin,cout,k,stride,pad
 ]
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("n,h,w,cin,cout,k,s,pad", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad):
+def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad, prec):
     lib, geom = _tg()
+    q = lambda a: _q(prec, a)
     rng = np.random.default_rng(0)
     x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
     wt = (rng.standard_normal((k, k, cin, cout)) * 0.1).astype(np.float32)
     bias = rng.standard_normal(cout).astype(np.float32)
     ci_p, co_p = geom.pad32(cin), geom.pad32(cout)
-    y_ref = T.lrelu(T.conv2d(x, wt, (s, s), pad) + bias)
+    y_ref = T.lrelu(T.conv2d(q(x), q(wt), (s, s), pad) + bias)
     ho, wo = y_ref.shape[1:3]
     scale = np.abs(x).max() * np.abs(wt).max() * k * k * cin
 
@@ -60,14 +72,14 @@ def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad):
     xd, wd, bd = dev(padc(x, ci_p)), dev(w_oti), dev(padc(bias, co_p))
     yd = torch.full((n, ho, wo, co_p), 7.0, device='cuda')
     d = geom.conv_fwd(n, h, w, ci_p, co_p, k, s, pad, act='lrelu')
-    lib.call("tg_igemm_f32", d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
+    lib.call("tg_igemm_" + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
     y = yd.cpu().numpy()
     close(y[..., :cout], y_ref, scale)
     assert (y[..., cout:] == 0).all()
 
     # input gradient: padded HWIO weights [k*k][ci_p][co_p]
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
-    dx_ref = T.conv2d_bwd_input(x.shape, wt, dy, (s, s), pad)
+    dx_ref = T.conv2d_bwd_input(x.shape, q(wt), q(dy), (s, s), pad)
     w_hwio = np.zeros((k * k, ci_p, co_p), np.float32)
     w_hwio[:, :cin, :cout] = wt.reshape(k * k, cin, cout)
     dyd, whd = dev(padc(dy, co_p)), dev(w_hwio)
@@ -75,17 +87,17 @@ def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad):
     descs = geom.conv_dgrad(n, h, w, ci_p, co_p, k, s, pad)
     assert len(descs) == s * s
     for dd in descs:
-        lib.call("tg_igemm_f32", dd, lib.ptr(dyd), lib.ptr(whd), None, lib.ptr(dxd), lib.cur_stream())
+        lib.call("tg_igemm_" + prec, dd, lib.ptr(dyd), lib.ptr(whd), None, lib.ptr(dxd), lib.cur_stream())
     dx = dxd.cpu().numpy()
     close(dx[..., :cin], dx_ref, np.abs(dy).max() * np.abs(wt).max() * k * k * cout)
     assert (dx[..., cin:] == 0).all()
 
     # filter gradient, 3 pixel splits summed on the host
-    dw_ref = T.conv2d_bwd_filter(x, dy, wt.shape, (s, s), pad)
+    dw_ref = T.conv2d_bwd_filter(q(x), q(dy), wt.shape, (s, s), pad)
     nsplit = 3
     slab = torch.full((nsplit, k * k, ci_p, co_p), 7.0, device='cuda')
     dw_desc = geom.conv_wgrad(n, h, w, ci_p, co_p, k, s, pad)
-    lib.call("tg_wgrad_f32", dw_desc, lib.ptr(xd), lib.ptr(dyd), lib.ptr(slab), nsplit, lib.cur_stream())
+    lib.call("tg_wgrad_" + prec, dw_desc, lib.ptr(xd), lib.ptr(dyd), lib.ptr(slab), nsplit, lib.cur_stream())
     dw = slab.cpu().numpy().sum(0)
     close(dw[:, :cin, :cout].reshape(wt.shape), dw_ref, np.abs(x).max() * np.abs(dy).max() * n * ho * wo)
     assert (dw[:, cin:, :] == 0).all() and (dw[:, :, cout:] == 0).all()
@@ -94,44 +106,47 @@ def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad):
 DECONV_CASES = [(3, 4, 4, 42, 64), (2, 8, 8, 74, 3), (5, 4, 4, 522, 256)]
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("n,h,w,cin,cout", DECONV_CASES)
-def test_deconv5x5s2_fwd_dgrad_wgrad(n, h, w, cin, cout):
+def test_deconv5x5s2_fwd_dgrad_wgrad(n, h, w, cin, cout, prec):
     lib, geom = _tg()
+    q = lambda a: _q(prec, a)
     rng = np.random.default_rng(1)
     x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
     wt = (rng.standard_normal((5, 5, cout, cin)) * 0.1).astype(np.float32)
     bias = rng.standard_normal(cout).astype(np.float32)
     ci_p, co_p = geom.pad32(cin), geom.pad32(cout)
-    y_ref = np.tanh(T.conv2d_transpose(x, wt) + bias)
+    y_ref = np.tanh(T.conv2d_transpose(q(x), q(wt)) + bias)
     w_pad = np.zeros((25, co_p, ci_p), np.float32)
     w_pad[:, :cout, :cin] = wt.reshape(25, cout, cin)
     xd, wd, bd = dev(padc(x, ci_p)), dev(w_pad), dev(padc(bias, co_p))
     # store only the logical channels (ld_out = cout) — the generator's last layer writes [N,32,32,3]
     yd = torch.full((n, 2 * h, 2 * w, cout), 7.0, device='cuda')
     for d in geom.deconv_fwd(n, h, w, ci_p, co_p, ld_out=cout, n_store=cout, act='tanh'):
-        lib.call("tg_igemm_f32", d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
+        lib.call("tg_igemm_" + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
     close(yd.cpu().numpy(), y_ref, np.abs(x).max() * np.abs(wt).max() * 9 * cin)
 
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
     dyd = dev(padc(dy, co_p))
-    dx_ref = T.conv2d_transpose_bwd_input(wt, dy)
+    dx_ref = T.conv2d_transpose_bwd_input(q(wt), q(dy))
     w_t = np.zeros((25, ci_p, co_p), np.float32)
     w_t[:, :cin, :cout] = wt.reshape(25, cout, cin).transpose(0, 2, 1)
     dxd = torch.full((n, h, w, ci_p), 7.0, device='cuda')
     wtd = dev(w_t)
-    lib.call("tg_igemm_f32", geom.deconv_dgrad(n, h, w, ci_p, co_p), lib.ptr(dyd), lib.ptr(wtd), None,
+    lib.call("tg_igemm_" + prec, geom.deconv_dgrad(n, h, w, ci_p, co_p), lib.ptr(dyd), lib.ptr(wtd), None,
              lib.ptr(dxd), lib.cur_stream())
     close(dxd.cpu().numpy()[..., :cin], dx_ref, np.abs(dy).max() * np.abs(wt).max() * 25 * cout)
 
-    dw_ref = T.conv2d_transpose_bwd_filter(x, dy, wt.shape)
+    dw_ref = T.conv2d_transpose_bwd_filter(q(x), q(dy), wt.shape)
     slab = torch.full((2, 25, co_p, ci_p), 7.0, device='cuda')
-    lib.call("tg_wgrad_f32", geom.deconv_wgrad(n, h, w, co_p, ci_p), lib.ptr(dyd), lib.ptr(xd), lib.ptr(slab), 2,
+    lib.call("tg_wgrad_" + prec, geom.deconv_wgrad(n, h, w, co_p, ci_p), lib.ptr(dyd), lib.ptr(xd), lib.ptr(slab), 2,
              lib.cur_stream())
     dw = slab.cpu().numpy().sum(0)
     close(dw[:, :cout, :cin].reshape(wt.shape), dw_ref, np.abs(x).max() * np.abs(dy).max() * n * h * w)
 
 
-def test_dense_and_identity_layout():
+@pytest.mark.parametrize("prec", PRECS)
+def test_dense_and_identity_layout(prec):
     """A = I with an asymmetric B catches a transposed C-write (cdna_hip_programming.md §3)."""
     lib, geom = _tg()
     m, kdim, nout = 200, 128, 96
@@ -142,11 +157,11 @@ def test_dense_and_identity_layout():
     wt = rng.standard_normal((nout, kdim)).astype(np.float32)      # Wt[n][k]
     yd = torch.zeros((m, nout), device='cuda')
     xd, wd = dev(x), dev(wt)      # keep the device buffers alive across the asynchronous launch
-    lib.call("tg_igemm_f32", geom.dense_fwd(m, kdim, nout), lib.ptr(xd), lib.ptr(wd), None, lib.ptr(yd),
+    lib.call("tg_igemm_" + prec, geom.dense_fwd(m, kdim, nout), lib.ptr(xd), lib.ptr(wd), None, lib.ptr(yd),
              lib.cur_stream())
     y = yd.cpu().numpy()
-    np.testing.assert_array_equal(y[:128], wt.T)                    # exact: one product per output
-    close(y[128:], x[128:] @ wt.T, np.abs(x).max() * np.abs(wt).max() * kdim)
+    np.testing.assert_array_equal(y[:128], _q(prec, wt).T)                    # exact: one product per output
+    close(y[128:], _q(prec, x[128:]) @ _q(prec, wt).T, np.abs(x).max() * np.abs(wt).max() * kdim)
 
 
 def test_bad_descriptor_is_rejected():

@@ -188,3 +188,64 @@ def test_philox_streams_are_distinct_and_well_distributed():
     lib.call('tg_rng_onehot_f32', lib.ptr(oh), 1000, 10, lib.ptr(state), 5, st())
     o = oh.cpu().numpy().reshape(1000, 10)
     assert (o.sum(1) == 1).all() and o.sum(0).min() > 50
+
+
+@pytest.mark.parametrize("prec", ['f32', 'bf16'])
+def test_fused_mean_only_batch_norm_forward_backward(prec):
+    """tg_igemm_colsum_{f32,bf16} + tg_mobn_apply_f32 (training and evaluation) and tg_mobn_bwd_f32 against the oracle's
+    conv2d + mean_only_batch_norm (Model/nn.py:147-187) applied per application segment, pop_mean updated sequentially."""
+    from tg import geom
+    lib = _lib()
+    q = (lambda a: T.bf16_round(a)) if prec == 'bf16' else (lambda a: a)
+    rng = np.random.default_rng(5)
+    segs, h, w, cin, cout = [2, 4, 1], 8, 8, 64, 128
+    n = sum(segs)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    pop0 = rng.standard_normal(cout).astype(np.float32)
+    seg_rows = [s * h * w for s in segs]
+    sa = (C.c_int32 * len(segs))(*seg_rows)
+    # oracle
+    y_ref, pop, o = [], pop0.astype(np.float64), 0
+    pre = T.conv2d(q(x).astype(np.float64), q(wt).astype(np.float64))
+    for s in segs:
+        yy, pop = T.mobn_train(pre[o:o + s], pop, b.astype(np.float64))
+        y_ref.append(T.lrelu(yy, 0.2))
+        o += s
+    y_ref = np.concatenate(y_ref)
+    # HIP
+    w_oti = np.zeros((cout, 9, cin), np.float32)
+    w_oti[:] = wt.reshape(9, cin, cout).transpose(2, 0, 1)
+    xd, wd, bd, popd = dev(x), dev(w_oti), dev(b), dev(pop0)
+    yd = torch.full((n, h, w, cout), 7.0, device='cuda')
+    sums = torch.zeros(2 * len(segs) * cout, device='cuda')          # nseg*c doubles
+    d = geom.conv_fwd(n, h, w, cin, cout, 3, 1, 'SAME')
+    lib.call('tg_igemm_colsum_' + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(yd), sa, len(segs), lib.ptr(sums), st())
+    pre_hip = yd.cpu().numpy().copy()
+    scale = np.abs(x).max() * np.abs(wt).max() * 9 * cin
+    assert np.abs(pre_hip - pre).max() <= 3e-5 * scale
+    lib.call('tg_mobn_apply_f32', lib.ptr(yd), cout, n * h * w, cout, sa, len(segs), lib.ptr(sums), lib.ptr(bd), lib.ptr(popd), 0.9,
+             lib.ACT['lrelu'], 0.2, st())
+    assert np.abs(yd.cpu().numpy() - y_ref).max() <= 3e-5 * scale
+    np.testing.assert_allclose(popd.cpu().numpy(), pop, rtol=2e-5, atol=2e-6)
+    # evaluation mode: sums = NULL -> x - pop_mean + b
+    ye = dev(pre_hip)
+    lib.call('tg_mobn_apply_f32', lib.ptr(ye), cout, n * h * w, cout, sa, len(segs), None, lib.ptr(bd), lib.ptr(popd), 0.9,
+             lib.ACT['lrelu'], 0.2, st())
+    np.testing.assert_allclose(ye.cpu().numpy(), T.lrelu(pre_hip - popd.cpu().numpy() + b, 0.2), rtol=1e-6, atol=1e-6)
+    # backward: dpre = dy*lrelu'(y) - mean_seg(...), db = sum over all rows
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    y_act = yd.cpu().numpy()
+    t = T.lrelu_bwd_from_out(y_act.astype(np.float64), dy.astype(np.float64), 0.2)
+    dx_ref, o = [], 0
+    for s in segs:
+        dxs, _ = T.mobn_train_bwd(t[o:o + s])
+        dx_ref.append(dxs)
+        o += s
+    dx_ref, db_ref = np.concatenate(dx_ref), t.sum(axis=(0, 1, 2))
+    dyd, dxd, dbd = dev(dy), torch.full((n, h, w, cout), 7.0, device='cuda'), torch.full((cout,), 7.0, device='cuda')
+    lib.call('tg_mobn_bwd_f32', lib.ptr(dyd), cout, lib.ptr(yd), cout, lib.ptr(dxd), cout, n * h * w, cout, sa, len(segs), lib.ACT['lrelu'], 0.2,
+             lib.ptr(sums), lib.ptr(dbd), st())
+    np.testing.assert_allclose(dxd.cpu().numpy(), dx_ref, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(dbd.cpu().numpy(), db_ref, rtol=1e-5, atol=1e-4)

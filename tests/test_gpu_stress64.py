@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def test_stress64_two_iterations():
     import torch
     from gpu_common import fresh_trainer
-    import stress64
+    import bench_config as stress64
     from Model.Good_GAN_stress64 import Good_GAN_stress64
     cfg = stress64.make_config()
     # a quarter of the batch keeps the test at a few hundred ms
