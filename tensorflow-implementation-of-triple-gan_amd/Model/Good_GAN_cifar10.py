@@ -44,6 +44,10 @@ G_DECONVS = [('gg_dconv0', 256), ('gg_dconv1', 128), ('gg_dconv2', 3)]      # (:
 
 class Good_GAN_cifar10(model_base.NN_Base):
     C_CONVS, D_CONVS, G_DECONVS = C_CONVS, D_CONVS, G_DECONVS
+    # data-parallel gradient buckets of the classifier: the variables created from C_BUCKET_FIRST on (87 % of
+    # the 12.5 MB) are final when the backward pass has returned to the end of block C_BUCKET_AFTER; their all-reduce then
+    # runs on RCCL's stream beside the backward pass of the first block
+    C_BUCKET_AFTER, C_BUCKET_FIRST = 'conv1_3', 'classifier/conv2_1/V'
 
     def __init__(self, config):
         super(Good_GAN_cifar10, self).__init__(config.BATCH_NORM_DECAY, config.BATCH_NORM_EPSILON)
@@ -162,6 +166,8 @@ class Good_GAN_cifar10(model_base.NN_Base):
             x = ops.im2col3x3_add(inp, noise)
             for i, (name, cout, pad, pool) in enumerate(self.C_CONVS):
                 x = nn.conv2d_WN(x, num_filters=cout, name=name, pad=pad, filter_size=[1, 1] if i == 0 else [3, 3], **kw)
+                if pool and name == self.C_BUCKET_AFTER:
+                    cx.grad_bucket_boundary()                                        # DP: gradients of the later layers are final here
                 if pool:                                                             # max_pool_k + dropout_k (:123-124,142-143)
                     mask = None
                     if is_training:

@@ -138,7 +138,8 @@ class Train(Train_base):
             if g_tape is not None:
                 cx.run_tape(g_tape)
 
-    def _c_forward_backward(self):
+    def _c_forward_backward(self, split=False):
+        """split: stop the backward pass at the model's gradient-bucket boundary (the rest runs in _c_backward_rest)."""
         c, cx, m = self.config, self.cx, self.model
         rep = bool(getattr(m, 'CONSISTENCY', False))       # Good_GAN_cifar10 only: second stochastic pass on x_u_c
         with cx.phase_scope('C', train_nets=('classifier',)):
@@ -157,7 +158,14 @@ class Train(Train_base):
                 _, d_unl = m.discriminator(self.x_u_c_ph, oh_unl)
             self._c_loss(c_logits, segs[0], segs[1], segs[1] if rep else 0, G.n, self.y_l_c_ph, self.y_g_ph, d_unl,
                          self.hyper[2:4], self.loss_dev[2:3])
-            cx.backward()
+            self._c_rest = (cx.backward(stop_at_boundary=split), cx.counter)
+
+    def _c_backward_rest(self):
+        rest, counter = self._c_rest
+        self._c_rest = None
+        if rest:
+            with self.cx.phase_scope('C', train_nets=('classifier',), counter=counter):
+                self.cx.run_tape(rest)
 
     def _c_apply(self):
         st = self.cx.stores['classifier']
@@ -167,16 +175,26 @@ class Train(Train_base):
         self.cx.rng.advance(self.cx)
 
     def _segments(self, pre_train=False):
+        """[(callable, flat gradient range to exchange afterwards or None, asynchronous?)] — each callable is one hipGraph.
+        With more than one replica the classifier's backward pass is cut at the model's bucket boundary: the gradients of
+        the later layers are all-reduced on RCCL's stream while the first block's backward pass still runs."""
         st = self.cx.stores
         w = 1.0 / self.world
+        gC = st['classifier'].g
+        first = getattr(self.model, 'C_BUCKET_FIRST', None)
+        split = self.world > 1 and first is not None and not getattr(self.config, 'NO_GRAD_BUCKETS', False)
+        if split:
+            off = st['classifier'].offset(first)
+            c_bwd = [(lambda: self._c_forward_backward(True), gC[off:], True), (self._c_backward_rest, gC[:off], False)]
+        else:
+            c_bwd = [(self._c_forward_backward, gC, False)]
         if pre_train:                                      # :182-226 only c_solver runs
-            return [(self._c_forward_backward, st['classifier']), (self._c_apply, None)]
+            return c_bwd + [(self._c_apply, None, False)]
+        c_bwd[0] = ((lambda f=c_bwd[0][0]: (self._train_op(self.g_optimizer, st['good_generator'], w), f())),) + c_bwd[0][1:]
         return [
-            (self._d_forward_backward, st['discriminator']),
-            (lambda: (self._train_op(self.d_optimizer, st['discriminator'], w), self._g_forward_backward()), st['good_generator']),
-            (lambda: (self._train_op(self.g_optimizer, st['good_generator'], w), self._c_forward_backward()), st['classifier']),
-            (self._c_apply, None),
-        ]
+            (self._d_forward_backward, st['discriminator'].g, False),
+            (lambda: (self._train_op(self.d_optimizer, st['discriminator'], w), self._g_forward_backward()), st['good_generator'].g, False),
+        ] + c_bwd + [(self._c_apply, None, False)]
 
     # ------------------------------------------------------------------ one iteration
     def feed(self, batch):
@@ -211,7 +229,12 @@ class Train(Train_base):
         if self._graphs is None:
             self._graphs = {}
         graphs = self._graphs.setdefault(key, [None] * len(segs))
-        for i, (fn, store) in enumerate(segs):
+        pending = []
+        for i, (fn, grads, overlap) in enumerate(segs):
+            if grads is None:                           # the classifier's optimiser step: needs every bucket
+                for wk in pending:
+                    tgdist.wait_(wk)
+                pending = []
             if use_graph and self._warm:
                 if graphs[i] is None:
                     import ctypes as C
@@ -225,8 +248,11 @@ class Train(Train_base):
                 lib.call('tg_graph_launch', graphs[i], cx.stream)
             else:
                 fn()
-            if store is not None and self.world > 1:
-                tgdist.allreduce_sum_(store.g)
+            if grads is not None and self.world > 1:
+                if overlap:
+                    pending.append(tgdist.allreduce_sum_async_(grads))
+                else:
+                    tgdist.allreduce_sum_(grads)
         self._warm = True
         self.iteration += 1
 

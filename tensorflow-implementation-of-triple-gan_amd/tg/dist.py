@@ -48,6 +48,20 @@ def allreduce_sum_(flat):
     return flat
 
 
+def allreduce_sum_async_(flat):
+    """Start the in-place sum on RCCL's own stream — it waits for what the current stream has enqueued so far and runs beside
+    whatever is enqueued next (the remaining backward pass).  Returns a handle for wait_(); None on one replica."""
+    if world_size() > 1:
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
+def wait_(work):
+    """make the CURRENT stream wait for an asynchronous collective (no host block with the nccl backend)."""
+    if work is not None:
+        work.wait()
+
+
 def allreduce_mean_(flat):
     if world_size() > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)

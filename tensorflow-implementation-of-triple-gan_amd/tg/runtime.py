@@ -116,6 +116,11 @@ class ParamStore(object):
     def enable_ema(self):
         self.ema = self.p.clone()
 
+    def offset(self, nm):
+        """element offset of trainable variable `nm` inside p / g / m / v (the gradient-bucket boundary of the DP exchange)."""
+        assert self.index[nm][0] == 'p', nm
+        return self.index[nm][1]
+
 
 class InjectedRNG(object):
     """Parity-test RNG: every draw is looked up in a dict of host arrays keyed '<rng_scope>/<name>'."""
@@ -253,10 +258,11 @@ class Context(object):
 
     # ---- phases / scopes -------------------------------------------------------------------------
     @contextlib.contextmanager
-    def phase_scope(self, name, train_nets=(), record=True):
-        """one solver run (sess.run of Training/Train_goodGAN.py:266-276): fresh call-site counter and tape."""
+    def phase_scope(self, name, train_nets=(), record=True, counter=0):
+        """one solver run (sess.run of Training/Train_goodGAN.py:266-276): fresh call-site counter and tape.
+        counter: resume value when a solver run is executed in two pieces (see Context.backward)."""
         prev = (self.phase, self.counter, self.tape, self.train_nets)
-        self.phase, self.counter = name, 0
+        self.phase, self.counter = name, counter
         self.tape = [] if record else None
         self.train_nets = set(train_nets)
         try:
@@ -278,7 +284,8 @@ class Context(object):
 
     def run_tape(self, tape):
         for fn in reversed(tape):
-            fn()
+            if fn is not BUCKET_BOUNDARY:
+                fn()
         del tape[:]
 
     @contextlib.contextmanager
@@ -326,10 +333,30 @@ class Context(object):
         if self.tape is not None:
             self.tape.append(fn)
 
-    def backward(self):
-        for fn in reversed(self.tape):
+    def grad_bucket_boundary(self):
+        """Called by a model between two layers of its forward pass: once the backward pass has come back to this point, the
+        variable gradients of every layer recorded AFTER it are final (data-parallel bucket boundary)."""
+        if self.tape is not None:
+            self.tape.append(BUCKET_BOUNDARY)
+
+    def backward(self, stop_at_boundary=False):
+        """Run the recorded closures in reverse.  stop_at_boundary: stop at the last grad_bucket_boundary() mark and return the
+        not-yet-executed head of the tape (run it later with run_tape inside phase_scope(..., counter=self.counter)), so that
+        the finished bucket can be all-reduced while the rest of the backward pass runs; None when everything ran."""
+        tape, self.tape = self.tape, []
+        i = len(tape)
+        while i > 0:
+            i -= 1
+            fn = tape[i]
+            if fn is BUCKET_BOUNDARY:
+                if stop_at_boundary:
+                    return tape[:i]
+                continue
             fn()
-        self.tape = []
+        return None
+
+
+BUCKET_BOUNDARY = object()
 
 
 _CTX = None

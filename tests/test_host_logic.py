@@ -163,3 +163,33 @@ def test_rampup_rampdown():
     from Training import Train_goodGAN as TG
     assert TG.rampup(300) == 1.0 and TG.rampdown(0) == 1.0
     assert abs(TG.rampup(0) - np.exp(-5.0)) < 1e-12
+
+
+def test_tape_split_at_gradient_bucket_boundary():
+    """Context.backward(stop_at_boundary=True): the closures recorded after the last boundary run, the head of the tape is
+    returned in order and runs later through run_tape (markers skipped) — the DP bucket protocol of SURVEY §8e."""
+    from tg import runtime
+    cx = runtime.Context.__new__(runtime.Context)          # tape logic only: no device needed
+    log = []
+    cx.tape = []
+    for i in range(3):
+        cx.record(lambda i=i: log.append('a%d' % i))
+    cx.grad_bucket_boundary()
+    for i in range(2):
+        cx.record(lambda i=i: log.append('b%d' % i))
+    cx.grad_bucket_boundary()
+    cx.record(lambda: log.append('c0'))
+    rest = cx.backward(stop_at_boundary=True)
+    assert log == ['c0'] and cx.tape == []
+    assert len(rest) == 6                                   # 3 + marker + 2
+    cx.run_tape(rest)
+    assert log == ['c0', 'b1', 'b0', 'a2', 'a1', 'a0'] and rest == []
+    # without the flag the markers are transparent
+    log[:] = []
+    cx.tape = []
+    cx.record(lambda: log.append('x'))
+    cx.grad_bucket_boundary()
+    cx.record(lambda: log.append('y'))
+    assert cx.backward() is None and log == ['y', 'x']
+    cx.tape = None
+    cx.grad_bucket_boundary()                               # no tape: no-op
