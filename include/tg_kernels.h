@@ -218,6 +218,10 @@ int tg_gavgpool_bwd_f32(const float* dfeat, int ld_d, const float* yact, int ld_
                         float alpha, void* stream);
 int tg_copy2d_f32(const float* src, int64_t ld_s, float* dst, int64_t ld_d, int64_t rows, int64_t c, void* stream);
 int tg_fill_f32(float* dst, float value, int64_t n, void* stream);
+/* input-pipeline tail on the device (Input_Pipeline/cifar10Dataset.py:52-62): dst = float(src)/255 * scale + shift
+ * (scale 2, shift -1 for SVHN / CIFAR-10; scale 1, shift 0 for MNIST, mnistDataset.py:65), and tf.one_hot(label, k). */
+int tg_u8_affine_f32(const uint8_t* src, float* dst, int64_t n, float scale, float shift, void* stream);
+int tg_onehot_i32_f32(const int32_t* labels, float* out, int64_t n, int k, void* stream);
 /* dst = a + b (dst may alias a or b): sums the per-application gradient buffers of a network applied several times. */
 int tg_add_f32(float* dst, const float* a, const float* b, int64_t n, void* stream);
 /* tf.one_hot(tf.argmax(logits,1)) (Good_GAN_cifar10.py:232,237,259,270); out [n][k]. */

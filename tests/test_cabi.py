@@ -9,10 +9,17 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "tg_kernels.h")
+IO_HEADER = os.path.join(ROOT, "include", "tg_io.h")
+
+
+def _declared(path):
+    text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    return set(re.findall(r"\b(tg_\w+)\s*\(", text)) - {"tg_status", "tg_igemm_desc"}
 
 
 def test_header_is_plain_c():
-    subprocess.check_call(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", HEADER])
+    for h in (HEADER, IO_HEADER):
+        subprocess.check_call(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", h])
 
 
 def test_library_exports_every_declared_symbol():
@@ -28,12 +35,15 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), name
     exported = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (tg_\w+)", exported))
-    assert exported == set(sigs), exported ^ set(sigs)       # nothing undeclared is exported either
+    io_syms = _declared(IO_HEADER)                           # host-side input pipeline (include/tg_io.h)
+    assert len(io_syms) == 10 and not (io_syms & set(sigs))
+    assert exported == set(sigs) | io_syms, exported ^ (set(sigs) | io_syms)       # nothing undeclared is exported either
 
 
 def test_no_torch_types_in_signatures():
-    text = open(HEADER).read()
-    assert "torch" not in text and "at::" not in text and "#include <hip" not in text
+    for h in (HEADER, IO_HEADER):
+        text = open(h).read()
+        assert "torch" not in text and "at::" not in text and "#include <hip" not in text
 
 
 def test_version_and_error_string_without_gpu(has_gpu):
