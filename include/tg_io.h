@@ -28,6 +28,10 @@ uint32_t tg_crc32c_masked(const void* data, int64_t n);
 /* Write (append != 0: append) n images [n][h][w][c] uint8 with their labels as one tf.Example per record. */
 int tg_tfrecord_write(const char* path, const uint8_t* images, const int64_t* labels, int64_t n, int h, int w, int c, int append);
 
+/* Frame ONE arbitrary payload as a TFRecord record and write / append it (TensorBoard event files, Training/Summary.py, are
+ * TFRecord files of Event protos). */
+int tg_record_append(const char* path, const void* payload, int64_t len, int append);
+
 /* Parse one serialized tf.Example: pointers INTO rec for the image bytes; label / height / width values.
  * Missing features are an error (tf.FixedLenFeature without default). */
 int tg_example_parse(const uint8_t* rec, int64_t len, const uint8_t** image, int64_t* image_len, int64_t* label, int64_t* height,

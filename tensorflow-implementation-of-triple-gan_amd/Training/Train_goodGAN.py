@@ -54,6 +54,11 @@ class Train(Train_base):
         self._graphs = None
         self._warm = False
         self.iteration = 0
+        self.summary_train = self.summary_val = None
+        if getattr(config, 'SUMMARY', False) and log_dir and self.rank == 0:          # :37-41
+            from Training.Summary import Summary
+            self.summary_train = Summary(log_dir, config, log_type='train', log_comments=kwargs.get('comments', ''))
+            self.summary_val = Summary(log_dir, config, log_type='val', log_comments=kwargs.get('comments', ''))
 
     # ------------------------------------------------------------------ graph build
     def _build_train_graph(self, Model):
@@ -278,6 +283,15 @@ class Train(Train_base):
         correct, total = counters.cpu().numpy()
         return float(correct) / max(float(total), 1.0)
 
+    def sync_running_state(self):
+        """Replicas keep their own running statistics (pop_mean, batch-norm moving mean / variance) and EMA shadows while
+        training; they are averaged over the replicas before evaluation and before a checkpoint is written."""
+        if self.world > 1:
+            for st in self.cx.stores.values():
+                tgdist.allreduce_mean_(st.s)
+                if st.ema is not None:
+                    tgdist.allreduce_mean_(st.ema)
+
     def sample(self, sample_z, sample_y):
         """model.good_sampler on fixed latents (:68,353-364) -> host array [N,H,W,C] in [-1,1]."""
         cx = self.cx
@@ -298,6 +312,20 @@ class Train(Train_base):
         sample_z = np.random.uniform(low=-1.0, high=1.0, size=(c.SAMPLE_SIZE, c.Z_DIM)).astype(np.float32)   # :130
         lr, cla_lr = c.LEARNING_RATE, getattr(c, 'CLA_LEARNINIG_RATE', c.LEARNING_RATE)
         start_epoch = 0
+        saver = None
+        if self.save_dir:
+            from Training.Saver import Saver
+            saver = Saver(self.save_dir)
+            if c.RESTORE:                                                              # :140-147
+                start_epoch = saver.restore(self, dir_names=c.RUN, epoch=c.RESTORE_EPOCH)
+                if start_epoch >= 300:
+                    lr = lr * 0.995 ** (start_epoch - 300)
+                    cla_lr = cla_lr * 0.99 ** (start_epoch - 300)
+            elif self.rank == 0:
+                saver.set_save_path(comments=self.comments)                            # :150
+        if self.summary_train is not None and getattr(c, 'SUMMARY_SCALAR', True):      # :105-118
+            self.summary_train.add_summary({'scalar': dict.fromkeys(('g_loss', 'd_loss', 'c_loss', 'train_accuracy'))})
+            self.summary_val.add_summary({'scalar': dict.fromkeys(('val_accuracy',))})
         history = []
         iters = int(c.TRAIN_SIZE / c.BATCH_SIZE)
         for epoch in range(1, c.EPOCHS + 1):
@@ -317,10 +345,16 @@ class Train(Train_base):
             torch.cuda.synchronize()
             dt = time.time() - t0
             init_op_val()
+            self.sync_running_state()
             acc = self.evaluate(NNIO.val_batches())
             rec = dict(epoch=epoch + start_epoch, d_loss=d_loss, g_loss=g_loss, c_loss=c_loss, val_accuracy=acc,
                        images_per_sec=iters * c.BATCH_SIZE * self.world / dt)
             history.append(rec)
+            if self.summary_train is not None:                                         # :293,346
+                self.summary_train.write(dict(g_loss=g_loss, d_loss=d_loss, c_loss=c_loss), epoch + start_epoch)
+                self.summary_val.write(dict(val_accuracy=acc), epoch + start_epoch)
+            if saver is not None and self.rank == 0 and epoch % c.SAVE_PER_EPOCH == 0:  # :366-369
+                saver.save(self, 'model_' + str(epoch + start_epoch).zfill(4) + '.ckpt')
             if self.rank == 0:
                 print("epoch {epoch}: g_loss {g_loss:.3f} d_loss {d_loss:.3f} c_loss {c_loss:.3f} val_acc {val_accuracy:.4f} "
                       "{images_per_sec:.0f} img/s".format(**rec), flush=True)
@@ -330,6 +364,8 @@ class Train(Train_base):
                     samples = self.sample(sample_z, sample_y)
                     save_images(samples, image_manifold_size(samples.shape[0]),
                                 os.path.join(c.SAMPLE_DIR, 'train_{:02d}.png'.format(epoch + start_epoch)))   # :359-363
+        if saver is not None and self.rank == 0 and c.EPOCHS > 0:                      # :378-379 (after all epochs)
+            saver.save(self, 'model_' + str(c.EPOCHS + start_epoch).zfill(4) + '.ckpt')
         return history
 
 

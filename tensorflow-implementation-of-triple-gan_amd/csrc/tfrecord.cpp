@@ -218,6 +218,21 @@ int tg_tfrecord_write(const char* path, const uint8_t* images, const int64_t* la
   return TG_OK;
 }
 
+int tg_record_append(const char* path, const void* payload, int64_t len, int append) {
+  TG_REQUIRE(path && (len == 0 || payload) && len >= 0, "record_append: bad arguments");
+  FILE* f = fopen(path, append ? "ab" : "wb");
+  TG_REQUIRE(f != nullptr, "record_append: cannot open %s", path);
+  const uint64_t n = (uint64_t)len;
+  uint8_t head[12];
+  memcpy(head, &n, 8);
+  const uint32_t c1 = mask_crc(crc32c(head, 8)), c2 = mask_crc(crc32c(static_cast<const uint8_t*>(payload), len));
+  memcpy(head + 8, &c1, 4);
+  const bool ok = fwrite(head, 1, 12, f) == 12 && (len == 0 || fwrite(payload, 1, (size_t)len, f) == (size_t)len) && fwrite(&c2, 1, 4, f) == 4;
+  const bool closed = fclose(f) == 0;
+  TG_REQUIRE(ok && closed, "record_append: short write to %s", path);
+  return TG_OK;
+}
+
 int tg_ds_open(const char* path, void** handle) {
   TG_REQUIRE(path && handle, "ds_open: null argument");
   Dataset* d = new Dataset();

@@ -19,6 +19,7 @@ def _lib():
         l.tg_crc32c_masked.argtypes = [C.c_void_p, C.c_int64]
         l.tg_crc32c_masked.restype = C.c_uint32
         l.tg_tfrecord_write.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
+        l.tg_record_append.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int]
         l.tg_example_parse.argtypes = [C.c_void_p, C.c_int64, C.POINTER(u8p), i64p, i64p, i64p, i64p]
         l.tg_ds_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         l.tg_ds_size.argtypes = [C.c_void_p]
@@ -27,7 +28,7 @@ def _lib():
         l.tg_ds_record.argtypes = [C.c_void_p, C.c_int64, C.POINTER(u8p), i64p]
         l.tg_ds_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
         l.tg_ds_close.argtypes = [C.c_void_p]
-        for n in ('tg_tfrecord_write', 'tg_example_parse', 'tg_ds_open', 'tg_ds_shape', 'tg_ds_record', 'tg_ds_gather', 'tg_ds_close'):
+        for n in ('tg_tfrecord_write', 'tg_record_append', 'tg_example_parse', 'tg_ds_open', 'tg_ds_shape', 'tg_ds_record', 'tg_ds_gather', 'tg_ds_close'):
             getattr(l, n).restype = C.c_int
         _typed = True
     return l
@@ -55,6 +56,12 @@ def write_tfrecord(path, images_u8, labels, append=False):
     n, h, w, c = img.shape
     assert lab.shape == (n,)
     _check(_lib().tg_tfrecord_write(str(path).encode(), img.ctypes.data, lab.ctypes.data, n, h, w, c, int(append)), 'tg_tfrecord_write')
+
+
+def append_record(path, payload, append=True):
+    """frame one payload as a TFRecord record and append it to `path`."""
+    b = bytes(payload)
+    _check(_lib().tg_record_append(str(path).encode(), b, len(b), int(append)), 'tg_record_append')
 
 
 def parse_example(payload):
