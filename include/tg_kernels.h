@@ -174,6 +174,17 @@ int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, flo
                     int act, float alpha, double* sums, float* db, void* stream);
 /* shift[s][k] = -sums[s][k]/rows_s; db[k] = sum_s sums[s][k]. */
 int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, int rows, int c, float* shift, float* db, void* stream);
+/* Fused training-mode batch norm over application segments (two launches): per segment s and column k
+ *   mean = sum x / n_s, var = sum x^2 / n_s - mean^2 (fp64), y = gamma*(x-mean)/sqrt(var+eps) + beta;
+ * mean_inv[s][0][k] = mean, mean_inv[s][1][k] = 1/sqrt(var+eps) (for the backward pass); the moving statistics (both NULL: none)
+ * are updated sequentially over the segments with the unbiased variance.  sums: scratch of 2*nseg*c doubles.  c need not be a
+ * multiple of 4 (columns up to the next multiple of 4 are read and written; they must lie inside ld). */
+int tg_bn_train_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int c, const int32_t* seg_rows, int nseg, const float* gamma,
+                    const float* beta, float eps, float decay, float* moving_mean, float* moving_var, double* sums, float* mean_inv, void* stream);
+/* its backward: dx = gamma*inv*(dy - mean_s(dy) - xhat*mean_s(dy*xhat)) per segment (masked by x > 0 when relu_input: the gradient is
+ * then with respect to the pre-ReLU value), dgamma = sum_s sum dy*xhat, dbeta = sum_s sum dy (both NULL: not wanted). */
+int tg_bn_train_bwd_f32(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
+                        const float* gamma, const float* mean_inv, int relu_input, double* sums, float* dgamma, float* dbeta, void* stream);
 /* batch norm (training mode, biased variance) from s1 = sum x and s2 = sum (x-mean)^2 (modes 0 and 4 above):
  * scale = gamma*inv, shift = beta - mean*scale, mean_inv = [mean | inv];
  * moving statistics updated in place when non-NULL (bessel = use the unbiased variance, the fused 4-D kernel). */

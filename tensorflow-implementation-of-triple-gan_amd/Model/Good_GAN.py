@@ -179,80 +179,50 @@ class Good_GAN(model_base.NN_Base):
                 raise NotImplementedError("MINIBATCH_DIS is off in every config of the reference (Train_goodGAN.py:502,578,656)")
             return None, self._WN_dense(h3, 1, 'd_h3_wndense', narrow=True)
 
-    def _classifier_one(self, image, train_ph):
+    def classifier(self, image, train_ph, reuse=False, segments=None):
+        """:212-350.  Returns (logits [N,10], feature).  `segments` (extension): image counts of the applications batched into
+        `image` — the convolutions run once over the whole batch, every batch norm keeps per-application statistics and
+        updates its moving statistics application by application (tg_bn_train_f32)."""
         cx = ctx()
         lre = self._leaky_relu
 
         def cbr(x, cname, bname, cout, k=3):
             x = self._conv2d(x, cout, k_h=k, k_w=k, d_h=1, d_w=1, name=cname, activation=lre)
-            return self._batch_norm_contrib(x, name=bname, train=train_ph)
+            return self._batch_norm_contrib(x, name=bname, train=train_ph, segments=segments)
 
         def pool_drop(x, key):
             mask = cx.rng.keep_mask(cx, key, x.rows // 4 * x.c, 0.5) if train_ph else None
             return ops.maxpool2_dropout(x, mask, 2.0)
 
-        if self.mnist:                                                                         # :216-247
-            img = ops.view(image, 28, 28, 1) if (image.h, image.w) == (1, 1) else image
-            noise = cx.rng.normal(cx, 'noise', img.rows * img.c, 0.3)
-            x = ops.im2col3x3_add(img, noise)                    # _add_noise + the 1-channel 3x3 window gathered once
-            x = cbr(x, 'c_h0_conv0', 'c_h0_bn0', 32, k=1)
-            x = pool_drop(x, 'drop1')
-            x = cbr(x, 'c_h1_conv0', 'c_h1_bn0', 64)
-            x = cbr(x, 'c_h1_conv1', 'c_h1_bn1', 64)
-            x = pool_drop(x, 'drop2')
-            x = cbr(x, 'c_h2_conv0', 'c_h2_bn0', 128)
-            x = cbr(x, 'c_h2_conv1', 'c_h2_bn1', 128)
-        else:                                                                                  # :249-299
-            image = self._drop_out(image, 0.2, train_ph, name='drop0')
-            x = ops.im2col3x3_add(image, None)
-            x = cbr(x, 'c_h0_conv0', 'c_h0_bn0', 128, k=1)
-            x = cbr(x, 'c_h0_conv1', 'c_h0_bn1', 128)
-            x = cbr(x, 'c_h0_conv2', 'c_h0_bn2', 128)
-            x = pool_drop(x, 'drop1')
-            x = cbr(x, 'c_h1_conv0', 'c_h1_bn0', 256)
-            x = cbr(x, 'c_h1_conv1', 'c_h1_bn1', 256)
-            x = cbr(x, 'c_h1_conv2', 'c_h1_bn2', 256)
-            x = pool_drop(x, 'drop2')
-            x = cbr(x, 'c_h2_conv0', 'c_h2_bn0', 512)
-            x = self._batch_norm_contrib(self._nin(x, 256, name='c_h2_nin0', activation=lre), name='c_h2_bn1', train=train_ph)
-            x = self._batch_norm_contrib(self._nin(x, 128, name='c_h2_nin1', activation=lre), name='c_h2_bn2', train=train_ph)
-        fm = ops.global_avgpool(x)                                                             # tf.reduce_mean(axis=[1,2])
-        h = self._linear_fc(fm, self.config.NUM_CLASSES, 'c_h2_lin')
-        return self._batch_norm_contrib(h, name='c_h3_bn0', train=train_ph), fm
-
-    def classifier(self, image, train_ph, reuse=False, segments=None):
-        """:212-350.  Returns (logits [N,10], feature)."""
-        cx = ctx()
         with cx.variable_scope('classifier'):
-            if segments is None or len(segments) == 1:
-                return self._classifier_one(image, train_ph)
-            # Every application writes (not accumulates) the gradients of the variables it used, so each one gets its own
-            # flat gradient buffer and the sum over applications — what tf.gradients returns for shared variables — is
-            # formed once all their backward passes have run (this closure is recorded first, hence executed last).
-            st = cx.stores['classifier']
-            trains = cx.trains()
-            real_g = st.g
-            bufs = [cx.ws('gapp:%s:%d' % (cx.phase, i), st.n_p) for i in range(len(segments))] if trains else []
-            if trains:
-                def sum_grads():
-                    from tg import lib
-                    lib.call('tg_add_f32', lib.ptr(real_g), lib.ptr(bufs[0]), lib.ptr(bufs[1]), st.n_p, cx.stream)
-                    for b in bufs[2:]:
-                        lib.call('tg_add_f32', lib.ptr(real_g), lib.ptr(real_g), lib.ptr(b), st.n_p, cx.stream)
-                cx.record(sum_grads)
-            outs, feats, off = [], [], 0
-            try:
-                for i, n in enumerate(segments):
-                    if trains:
-                        st.g = bufs[i]
-                    with cx.rng_scoped('%s/s%d' % (cx.rng_scope, i)):
-                        lg, fm = self._classifier_one(image.view_rows(off, off + n), train_ph)
-                    outs.append(lg)
-                    feats.append(fm)
-                    off += n
-            finally:
-                st.g = real_g
-            return ops.concat_batch(outs), ops.concat_batch(feats)
+            if self.mnist:                                                                         # :216-247
+                img = ops.view(image, 28, 28, 1) if (image.h, image.w) == (1, 1) else image
+                noise = cx.rng.normal(cx, 'noise', img.rows * img.c, 0.3)
+                x = ops.im2col3x3_add(img, noise)                    # _add_noise + the 1-channel 3x3 window gathered once
+                x = cbr(x, 'c_h0_conv0', 'c_h0_bn0', 32, k=1)
+                x = pool_drop(x, 'drop1')
+                x = cbr(x, 'c_h1_conv0', 'c_h1_bn0', 64)
+                x = cbr(x, 'c_h1_conv1', 'c_h1_bn1', 64)
+                x = pool_drop(x, 'drop2')
+                x = cbr(x, 'c_h2_conv0', 'c_h2_bn0', 128)
+                x = cbr(x, 'c_h2_conv1', 'c_h2_bn1', 128)
+            else:                                                                                  # :249-299
+                image = self._drop_out(image, 0.2, train_ph, name='drop0')
+                x = ops.im2col3x3_add(image, None)
+                x = cbr(x, 'c_h0_conv0', 'c_h0_bn0', 128, k=1)
+                x = cbr(x, 'c_h0_conv1', 'c_h0_bn1', 128)
+                x = cbr(x, 'c_h0_conv2', 'c_h0_bn2', 128)
+                x = pool_drop(x, 'drop1')
+                x = cbr(x, 'c_h1_conv0', 'c_h1_bn0', 256)
+                x = cbr(x, 'c_h1_conv1', 'c_h1_bn1', 256)
+                x = cbr(x, 'c_h1_conv2', 'c_h1_bn2', 256)
+                x = pool_drop(x, 'drop2')
+                x = cbr(x, 'c_h2_conv0', 'c_h2_bn0', 512)
+                x = self._batch_norm_contrib(self._nin(x, 256, name='c_h2_nin0', activation=lre), name='c_h2_bn1', train=train_ph, segments=segments)
+                x = self._batch_norm_contrib(self._nin(x, 128, name='c_h2_nin1', activation=lre), name='c_h2_bn2', train=train_ph, segments=segments)
+            fm = ops.global_avgpool(x)                                                             # tf.reduce_mean(axis=[1,2])
+            h = self._linear_fc(fm, self.config.NUM_CLASSES, 'c_h2_lin')
+            return self._batch_norm_contrib(h, name='c_h3_bn0', train=train_ph, segments=segments), fm
 
     def forward_pass(self, z_g, y_g, x_l_c, y_l_c, x_l_d, y_l_d, x_u_d, x_u_c, train):
         """:428-472 (evaluation / tests; the trainer runs per-solver sub-graphs)."""

@@ -91,9 +91,10 @@ class NN_Base(object):
                                 kernel_grad=cx.var_grad('kernel') if tr else None, bias_grad=cx.var_grad('bias') if tr else None,
                                 narrow_out=narrow)
 
-    def _batch_norm_contrib(self, x, name, train=False):
+    def _batch_norm_contrib(self, x, name, train=False, segments=None):
         """tf.contrib.layers.batch_norm(decay, eps, scale=True, updates_collections=None) (modle_base.py:229-237).
-        train=True: batch statistics, moving statistics updated in place; train=False: moving statistics."""
+        train=True: batch statistics, moving statistics updated in place; train=False: moving statistics.
+        segments (extension): image counts of the applications batched into x — statistics per application."""
         cx = ctx()
         with cx.variable_scope(name):
             if not train:
@@ -102,7 +103,8 @@ class NN_Base(object):
             tr = cx.trains()
             return ops.batch_norm_train(x, cx.var('gamma'), cx.var('beta'), cx.var('moving_mean'), cx.var('moving_variance'),
                                         self._batch_norm_epsilon, self._batch_norm_decay,
-                                        gamma_grad=cx.var_grad('gamma') if tr else None, beta_grad=cx.var_grad('beta') if tr else None)
+                                        gamma_grad=cx.var_grad('gamma') if tr else None, beta_grad=cx.var_grad('beta') if tr else None,
+                                        segments=segments)
 
     def _WN_dense(self, input_, output_size, scope, init_scale=1.0, init=False, activation=None, narrow=False):
         """g * (x @ l2_normalize(V,[0])) + b (modle_base.py:50-73; the data-dependent init branch is never taken)."""

@@ -387,6 +387,193 @@ __global__ void bn_bwd_finalize(const float* __restrict__ s_dy, const float* __r
   abc[2 * c + col] = -A * dbt / m - B * mu;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused training-mode batch norm (tf.contrib.layers.batch_norm, Model/modle_base.py:229-237) over application segments:
+// two launches per direction instead of six / four.
+//   sums   : per (segment, column) fp64 accumulators filled with one atomic per column per workgroup;
+//            forward  S0 = sum x, S1 = sum x^2   (variance = S1/n - mean^2 evaluated in fp64: no cancellation problem)
+//            backward S0 = sum dy, S1 = sum dy*x
+//   apply  : every workgroup derives the per-column coefficients of its segment in LDS and streams its rows;
+//            the first workgroup of a column block also writes mean / inv-std (forward) or dgamma / dbeta (backward)
+//            and updates the moving statistics, sequentially over the segments (= call-site order of the applications).
+// Work decomposition: blockIdx.x enumerates row chunks segment by segment (a chunk never straddles two segments, whatever
+// their sizes), blockIdx.y column blocks of BN_CW columns.
+constexpr int BN_CW = 256;
+
+__device__ __forceinline__ bool bn_chunk(const SegTable& st, int chunk, int bid, int* seg, int* r0, int* r1) {
+  int base = 0;
+  for (int s = 0; s < st.nseg; ++s) {
+    const int n = (st.rows[s] + chunk - 1) / chunk;
+    if (bid < n) {
+      *seg = s;
+      *r0 = base + bid * chunk;
+      *r1 = min(base + st.rows[s], *r0 + chunk);
+      return true;
+    }
+    bid -= n;
+    base += st.rows[s];
+  }
+  return false;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) bn_sums(const float* __restrict__ a, int ld_a, const float* __restrict__ b, int ld_b, int c, SegTable st,
+                                               int chunk, double* __restrict__ sums) {
+  int seg, r0, r1;
+  if (!bn_chunk(st, chunk, blockIdx.x, &seg, &r0, &r1)) return;
+  const int c0 = blockIdx.y * BN_CW;
+  const int cgn = min((c - c0 + 3) / 4, BN_CW / 4);          // column groups of this block
+  const int lanes = 256 / cgn;
+  const int cg = threadIdx.x % cgn, rl = threadIdx.x / cgn;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (rl < lanes) {
+    for (int r = r0 + rl; r < r1; r += lanes) {
+      const float4 av = *reinterpret_cast<const float4*>(a + (int64_t)r * ld_a + c0 + cg * 4);
+      const float as[4] = {av.x, av.y, av.z, av.w};
+      if (BWD) {
+        const float4 bv = *reinterpret_cast<const float4*>(b + (int64_t)r * ld_b + c0 + cg * 4);
+        const float bs[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0[k] += (double)as[k]; s1[k] += (double)as[k] * (double)bs[k]; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0[k] += (double)as[k]; s1[k] += (double)as[k] * (double)as[k]; }
+      }
+    }
+  }
+  __shared__ double red[256 * 8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[threadIdx.x * 8 + k] = s0[k]; red[threadIdx.x * 8 + 4 + k] = s1[k]; }
+  __syncthreads();
+  if (rl == 0) {
+    for (int l = 1; l < lanes; ++l)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s0[k] += red[(l * cgn + cg) * 8 + k]; s1[k] += red[(l * cgn + cg) * 8 + 4 + k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int col = c0 + cg * 4 + k;
+      if (col < c) {
+        atomicAdd(sums + ((int64_t)seg * 2 + 0) * c + col, s0[k]);
+        atomicAdd(sums + ((int64_t)seg * 2 + 1) * c + col, s1[k]);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_train_apply(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int c, SegTable st, int chunk,
+                                                      const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, float decay, float* __restrict__ mm, float* __restrict__ mv,
+                                                      float* __restrict__ mean_inv) {
+  int seg, r0, r1;
+  if (!bn_chunk(st, chunk, blockIdx.x, &seg, &r0, &r1)) return;
+  const int c0 = blockIdx.y * BN_CW;
+  const int ncol = min(c - c0, BN_CW);
+  __shared__ float sc[BN_CW], sh[BN_CW];
+  for (int k = threadIdx.x; k < BN_CW; k += 256) {
+    float a = 0.f, b = 0.f;
+    if (k < ncol) {
+      const int col = c0 + k;
+      const double n = (double)st.rows[seg];
+      const double mu = sums[((int64_t)seg * 2) * c + col] / n;
+      double var = sums[((int64_t)seg * 2 + 1) * c + col] / n - mu * mu;
+      var = var > 0. ? var : 0.;
+      const float inv = 1.f / sqrtf((float)var + eps);
+      a = gamma[col] * inv;
+      b = beta[col] - (float)mu * a;
+    }
+    sc[k] = a; sh[k] = b;
+  }
+  // first workgroup of this column block: per-segment mean / inv-std for the backward pass, moving statistics in segment order
+  if (blockIdx.x == 0) {
+    for (int k = threadIdx.x; k < ncol; k += 256) {
+      const int col = c0 + k;
+      float m_run = mm ? mm[col] : 0.f, v_run = mv ? mv[col] : 0.f;
+      for (int s = 0; s < st.nseg; ++s) {
+        const double n = (double)st.rows[s];
+        const double mu = sums[((int64_t)s * 2) * c + col] / n;
+        double var = sums[((int64_t)s * 2 + 1) * c + col] / n - mu * mu;
+        var = var > 0. ? var : 0.;
+        mean_inv[((int64_t)s * 2) * c + col] = (float)mu;
+        mean_inv[((int64_t)s * 2 + 1) * c + col] = 1.f / sqrtf((float)var + eps);
+        const float vb = st.rows[s] > 1 ? (float)var * ((float)st.rows[s] / (float)(st.rows[s] - 1)) : (float)var;   // Bessel, as the fused TF op
+        m_run = m_run * decay + (float)mu * (1.f - decay);
+        v_run = v_run * decay + vb * (1.f - decay);
+      }
+      if (mm) { mm[col] = m_run; mv[col] = v_run; }
+    }
+  }
+  __syncthreads();
+  const int cgn = (ncol + 3) / 4;
+  const int total = (r1 - r0) * cgn;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int rr = i / cgn, cg = i - rr * cgn;
+    const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + rr) * ld_x + c0 + cg * 4);
+    float4 o;
+    o.x = xv.x * sc[cg * 4] + sh[cg * 4];
+    o.y = xv.y * sc[cg * 4 + 1] + sh[cg * 4 + 1];
+    o.z = xv.z * sc[cg * 4 + 2] + sh[cg * 4 + 2];
+    o.w = xv.w * sc[cg * 4 + 3] + sh[cg * 4 + 3];
+    *reinterpret_cast<float4*>(y + (int64_t)(r0 + rr) * ld_y + c0 + cg * 4) = o;
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_train_bwd_apply(const float* __restrict__ dy, int ld_dy, const float* __restrict__ x, int ld_x,
+                                                          float* __restrict__ dx, int ld_dx, int c, SegTable st, int chunk,
+                                                          const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                          const float* __restrict__ mean_inv, int relu_mask, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
+  int seg, r0, r1;
+  if (!bn_chunk(st, chunk, blockIdx.x, &seg, &r0, &r1)) return;
+  const int c0 = blockIdx.y * BN_CW;
+  const int ncol = min(c - c0, BN_CW);
+  __shared__ float A[BN_CW], B[BN_CW], Cc[BN_CW];
+  for (int k = threadIdx.x; k < BN_CW; k += 256) {
+    float a = 0.f, b = 0.f, cc = 0.f;
+    if (k < ncol) {
+      const int col = c0 + k;
+      const float mu = mean_inv[((int64_t)seg * 2) * c + col], inv = mean_inv[((int64_t)seg * 2 + 1) * c + col], g = gamma[col];
+      const float m = (float)st.rows[seg];
+      const float dbt = (float)sums[((int64_t)seg * 2) * c + col];
+      const float dgm = inv * (float)(sums[((int64_t)seg * 2 + 1) * c + col] - (double)mu * sums[((int64_t)seg * 2) * c + col]);   // sum dy * xhat
+      a = g * inv;
+      b = -g * inv * inv * dgm / m;
+      cc = -a * dbt / m - b * mu;
+    }
+    A[k] = a; B[k] = b; Cc[k] = cc;
+  }
+  if (blockIdx.x == 0 && dgamma) {
+    for (int k = threadIdx.x; k < ncol; k += 256) {
+      const int col = c0 + k;
+      double dg = 0., db = 0.;
+      for (int s = 0; s < st.nseg; ++s) {
+        const double mu = (double)mean_inv[((int64_t)s * 2) * c + col], inv = (double)mean_inv[((int64_t)s * 2 + 1) * c + col];
+        const double sdy = sums[((int64_t)s * 2) * c + col];
+        db += sdy;
+        dg += inv * (sums[((int64_t)s * 2 + 1) * c + col] - mu * sdy);
+      }
+      dgamma[col] = (float)dg;
+      dbeta[col] = (float)db;
+    }
+  }
+  __syncthreads();
+  const int cgn = (ncol + 3) / 4;
+  const int total = (r1 - r0) * cgn;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int rr = i / cgn, cg = i - rr * cgn;
+    const float4 g = *reinterpret_cast<const float4*>(dy + (int64_t)(r0 + rr) * ld_dy + c0 + cg * 4);
+    const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + rr) * ld_x + c0 + cg * 4);
+    const float gs[4] = {g.x, g.y, g.z, g.w}, xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float t = A[cg * 4 + k] * gs[k] + B[cg * 4 + k] * xs[k] + Cc[cg * 4 + k];
+      if (relu_mask && !(xs[k] > 0.f)) t = 0.f;
+      v[k] = t;
+    }
+    *reinterpret_cast<float4*>(dx + (int64_t)(r0 + rr) * ld_dx + c0 + cg * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 int make_segs(SegTable& st, const int32_t* seg_rows, int nseg, int rows) {
   TG_REQUIRE(nseg >= 1 && nseg <= MAXSEG, "nseg=%d out of range", nseg);
   int tot = 0;
@@ -549,6 +736,60 @@ int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nse
   tg::ProfScope prof(tg::PC_NORM, 0, 0, s);
   hipLaunchKernelGGL(mobn_bwd_finalize, dim3((c + 127) / 128), dim3(128), 0, s, sums, st, c, shift, db);
   TG_CHECK_LAUNCH("mobn_bwd_finalize");
+  return TG_OK;
+}
+
+static int bn_grid(const SegTable& st, int rows, int c, int* chunk, dim3* grid) {
+  // ~1024 row chunks (multiples of 32 rows) over all segments; every segment contributes at least one
+  int ch = ((rows + 1023) / 1024 + 31) / 32 * 32;
+  if (ch < 32) ch = 32;
+  int n = 0;
+  for (int s = 0; s < st.nseg; ++s) n += (st.rows[s] + ch - 1) / ch;
+  *chunk = ch;
+  *grid = dim3(n, (c + BN_CW - 1) / BN_CW);
+  return TG_OK;
+}
+
+int tg_bn_train_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int c, const int32_t* seg_rows, int nseg, const float* gamma,
+                    const float* beta, float eps, float decay, float* moving_mean, float* moving_var, double* sums, float* mean_inv, void* stream) {
+  SegTable st;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(x && y && gamma && beta && sums && mean_inv, "bn_train: null buffer");
+  TG_REQUIRE(c > 0 && ld_x % 4 == 0 && ld_y % 4 == 0 && (c + 3) / 4 * 4 <= ld_x && (c + 3) / 4 * 4 <= ld_y, "bn_train: c=%d vs ld=%d/%d", c, ld_x, ld_y);
+  TG_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_train: moving_mean / moving_var must both be given or both be NULL");
+  hipStream_t s = tg::as_stream(stream);
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * nseg * c, s);
+  if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn sums)");
+  tg::ProfScope prof(tg::PC_NORM, 0, 12.0 * rows * c, s);
+  int chunk; dim3 grid;
+  bn_grid(st, rows, c, &chunk, &grid);
+  hipLaunchKernelGGL(bn_sums<false>, grid, dim3(256), 0, s, x, ld_x, (const float*)nullptr, 0, c, st, chunk, sums);
+  TG_CHECK_LAUNCH("bn_sums");
+  hipLaunchKernelGGL(bn_train_apply, grid, dim3(256), 0, s, x, ld_x, y, ld_y, c, st, chunk, sums, gamma, beta, eps, decay, moving_mean, moving_var, mean_inv);
+  TG_CHECK_LAUNCH("bn_train_apply");
+  return TG_OK;
+}
+
+int tg_bn_train_bwd_f32(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
+                        const float* gamma, const float* mean_inv, int relu_input, double* sums, float* dgamma, float* dbeta, void* stream) {
+  SegTable st;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(dy && x && dx && gamma && mean_inv && sums, "bn_train_bwd: null buffer");
+  TG_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_train_bwd: dgamma / dbeta must both be given or both be NULL");
+  const int cp = (c + 3) / 4 * 4;
+  TG_REQUIRE(c > 0 && ld_dy % 4 == 0 && ld_x % 4 == 0 && ld_dx % 4 == 0 && cp <= ld_dy && cp <= ld_x && cp <= ld_dx, "bn_train_bwd: c=%d vs ld", c);
+  hipStream_t s = tg::as_stream(stream);
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * nseg * c, s);
+  if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn bwd sums)");
+  tg::ProfScope prof(tg::PC_NORM, 0, 20.0 * rows * c, s);
+  int chunk; dim3 grid;
+  bn_grid(st, rows, c, &chunk, &grid);
+  hipLaunchKernelGGL(bn_sums<true>, grid, dim3(256), 0, s, dy, ld_dy, x, ld_x, c, st, chunk, sums);
+  TG_CHECK_LAUNCH("bn_sums<bwd>");
+  hipLaunchKernelGGL(bn_train_bwd_apply, grid, dim3(256), 0, s, dy, ld_dy, x, ld_x, dx, ld_dx, c, st, chunk, sums, gamma, mean_inv, relu_input, dgamma, dbeta);
+  TG_CHECK_LAUNCH("bn_train_bwd_apply");
   return TG_OK;
 }
 

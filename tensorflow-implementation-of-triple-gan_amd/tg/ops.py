@@ -235,35 +235,34 @@ def batch_norm_eval(x, gamma, beta, mm, mv, eps):
     return y
 
 
-def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_grad=None, relu_input=False):
-    """y = gamma*(x-mu)/sqrt(var+eps)+beta over all rows (Model/modle_base.py:229-237).
+def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_grad=None, relu_input=False, segments=None):
+    """y = gamma*(x-mu)/sqrt(var+eps)+beta over all rows (Model/modle_base.py:229-237); with `segments` (image counts of the
+    applications batched into x) the statistics are per application and the moving statistics are updated application by
+    application.  Fused: one statistics launch (fp64 atomics) + one apply launch per direction.
     relu_input: x is the output of a fused ReLU; the backward then also masks by x > 0 and the
     gradient it produces is wrt the PRE-ReLU value (consumed by the producing conv's backward)."""
     cx = ctx()
     c = x.c
     trains = cx.trains()
     needs = cx.tape is not None and (x.requires_grad or trains)
-    s1, _ = colstats(0, x.t, x.ld, None, 0, x.rows, c, [x.rows])
-    s2, _ = colstats(4, x.t, x.ld, s1, 0, x.rows, c, [x.rows], alpha=1.0 / x.rows)   # centred second pass (tf.nn.moments)
-    scale, shift, mean_inv = cx.scratch('bnsc', c), cx.scratch('bnsh', c), cx.scratch('bnmi', 2 * c)
-    _call('tg_bn_finalize_f32', _p(s1), _p(s2), x.rows, c, _p(gamma), _p(beta), eps, _p(scale), _p(shift), _p(mean_inv), _p(mm), _p(mv),
-          decay, 1, cx.stream)
+    seg_rows = _segs(x, segments)
+    nseg = len(seg_rows)
+    sums = cx.scratch('bn64', 4 * nseg * c)                   # 2*nseg*c doubles
+    mean_inv = cx.scratch('bnmi', 2 * nseg * c)
     y = cx.new_act(x.n, x.h, x.w, c, x.ld, requires_grad=needs)
-    _call('tg_seg_scale_shift_act_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, c, seg_array([x.rows]), 1, _p(scale), _p(shift), 0, 0.0,
-          cx.stream)
+    _call('tg_bn_train_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, seg_array(seg_rows), nseg, _p(gamma), _p(beta), eps, decay, _p(mm), _p(mv),
+          _p(sums), _p(mean_inv), cx.stream)
     if not needs:
         return y
 
     def bwd():
         gy = y.grad
         assert gy is not None
-        sdy, sdyx = colstats(3, gy.t, gy.ld, x.t, x.ld, x.rows, c, [x.rows])
-        abc = cx.scratch('abc', 3 * c)
-        dg = gamma_grad if (trains and gamma_grad is not None) else cx.scratch('dgm', c)
-        db = beta_grad if (trains and beta_grad is not None) else cx.scratch('dbt', c)
-        _call('tg_bn_bwd_finalize_f32', _p(sdy), _p(sdyx), x.rows, c, _p(gamma), _p(mean_inv), _p(abc), _p(dg), _p(db), cx.stream)
+        want = trains and gamma_grad is not None
         gx = cx.grad_of(x)
-        _call('tg_bn_bwd_apply_f32', gy.ptr, gy.ld, x.ptr, x.ld, gx.ptr, gx.ld, x.rows, c, _p(abc), 1 if relu_input else 0, cx.stream)
+        bsums = cx.scratch('bnb64', 4 * nseg * c)
+        _call('tg_bn_train_bwd_f32', gy.ptr, gy.ld, x.ptr, x.ld, gx.ptr, gx.ld, x.rows, c, seg_array(seg_rows), nseg, _p(gamma), _p(mean_inv),
+              1 if relu_input else 0, _p(bsums), _p(gamma_grad) if want else None, _p(beta_grad) if want else None, cx.stream)
 
     cx.record(bwd)
     return y

