@@ -35,6 +35,12 @@ def main():
             CHANNEL = 3
             NUM_CLASSES = 10
             REPEAT = -1
+            Z_DIM = 100
+            NUM_LABEL = 4000
+            FAKE_G_LAMBDA = 0.3
+            CLA_LEARNINIG_RATE = 3e-3
+            TRAIN_SIZE = 46000
+            EPOCHS = 1
         cfg = Cfg()
         tr = cifar10Dataset(d, cfg, n_lab, 'train', True)
         te = cifar10Dataset(d, cfg, n_lab, 'test', False)
@@ -72,6 +78,26 @@ def main():
             out['feeds_per_s'] = round(iters / dt, 1)
             out['real_images_per_s_into_hbm'] = round(iters * 200 / dt)
             out['nominal_images_per_s_sustained'] = round(iters * 100 / dt)
+            # the training step fed from the files every iteration (PCIe-inclusive rate of the bench.py workload)
+            from Training.Train_goodGAN import Train
+            from Model.Good_GAN_cifar10 import Good_GAN_cifar10
+            q, _ = np.linalg.qr(np.random.default_rng(4321).standard_normal((3072, 3072)))
+            cfg.ZCA = (np.zeros(3072, np.float32), q.astype(np.float32))
+            cfg.SUMMARY = False
+            trn = Train(cfg, None, None)
+            trn._build_train_graph(Good_GAN_cifar10)
+            trn.set_hyper(3e-4, 3e-3, 0.3, 0.5)
+            for _ in range(3):
+                trn.feed(nnio.next()); trn.sample_latent(); trn.train_iteration()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            steps = 100
+            for _ in range(steps):
+                trn.feed(nnio.next()); trn.sample_latent(); trn.train_iteration()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out['train_from_tfrecords'] = dict(images_per_sec=round(steps * 100 / dt, 1), ms_per_step=round(dt / steps * 1e3, 3),
+                                               note='CIFAR-10 config, fp32, hipGraph; every iteration decoded from TFRecord files, copied over PCIe (uint8) and scaled on the device')
     print(json.dumps(out), flush=True)
 
 
