@@ -408,7 +408,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
 
   const tg_igemm_desc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int b = blockIdx.x;
+  // XCD-aware order: consecutive logical workgroups (the tiles and the 9 taps of one pixel split, which stream the same
+  // `dout` rows and neighbouring `in` rows at the same pace) run on ONE XCD and meet in its L2
+  int b = xcd_remap(blockIdx.x, gridDim.x);
   const int nt = b % p.n_tiles; b /= p.n_tiles;
   const int ct = b % p.c_tiles; b /= p.c_tiles;
   const int tap = b % d.n_taps;
