@@ -67,7 +67,12 @@ def algorithmic_flops(s=SIZES):
 
 def make_config(rank):
     from config import Config
-    from oracle.step_cifar10 import synth_zca      # synthetic ZCA constants only (data generation, not compute)
+
+    def synth_zca(seed=4321, dim=3072):
+        """SURVEY §8d synthetic whitening constants: mean 0, seeded random orthogonal matrix (the real cifar10_zca_*.npy are not
+        part of the reference repository).  Generated here: the timed path imports nothing from oracle/."""
+        q, _ = np.linalg.qr(np.random.default_rng(seed).standard_normal((dim, dim)))
+        return np.zeros(dim, np.float32), q.astype(np.float32)
 
     class TempConfig(Config):
         NAME = "Good_GAN"
@@ -216,15 +221,16 @@ def main():
     achieved = fl['executed_igemm'] / (ig['ms_per_iter'] * 1e-3) / 1e12
     n_conv_launches = (conv_n['igemm_f32'] + conv_n['wgrad_f32']) / args.prof_iters
     # HBM bytes of the dominant launch from the PMC passes stored under profiles/ (rocprofv3 cannot run inside this process)
-    traffic = None
+    traffic, traffic_detail = None, None
     tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
     if os.path.exists(tfile):
         tj = json.load(open(tfile))['dominant_launch']
-        traffic = dict(bytes_per_launch=tj['traffic_bytes_corrected'], algorithmic_bytes_per_launch=tj['algorithmic_bytes'], kernel=tj['kernel'],
-                       source='profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)')
+        traffic = tj['traffic_bytes_corrected']
+        traffic_detail = dict(algorithmic_bytes_per_launch=tj['algorithmic_bytes'], kernel=tj['kernel'],
+                              source='profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950-corrected)')
     roofline = dict(bound="mfma", kernel="classifier 3x3 conv path: igemm_f32_kernel (fwd + input grad) + wgrad_f32_kernel",
                     achieved=round(conv_tf, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(conv_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                    traffic=traffic, launches_per_step=n_conv_launches,
+                    traffic=traffic, traffic_detail=traffic_detail, launches_per_step=n_conv_launches,
                     avg_launch_ms=round((conv_ms['igemm_f32'] + conv_ms['wgrad_f32']) / max(n_conv_launches, 1), 5),
                     algorithmic_gflop_per_step=round((conv_fl_ig + conv_fl_wg) / 1e9, 1),
                     conv3x3_igemm=dict(achieved=round(conv_tf_ig, 2), ms_per_step=round(conv_ms['igemm_f32'], 3)),

@@ -32,7 +32,7 @@ GRAD_MAX_TOL = 5e-2  # max |g_hip - g_f64| / max |g_f64| per variable (+1e-7 abs
                      # Why not tighter: the networks are full of kinks (ReLU / leaky-ReLU masks, 2x2 and global max-pool
                      # arg-max).  Forward values agree to ~1e-5, so of the millions of activations a few hundred sit
                      # closer to a kink than that and take the other branch on the two sides; each such flip moves one
-                     # gradient element by O(1).  Variables behind no such flip agree to 1e-5..1e-4 (tools/debug_*).
+                     # gradient element by O(1).  Variables behind no such flip agree to 1e-5..1e-4 (tests/debug/debug_*).
 NETS = {'D': 'discriminator', 'G': 'good_generator', 'C': 'classifier'}
 
 
