@@ -72,7 +72,8 @@ def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst):
     ns = wgrad_splits(desc, m)
     slab = cx.scratch('slab', ns * t * desc.ld_in * desc.c_out)
     _call('tg_wgrad_f32', desc, _p(in_act_t), _p(dout_t), _p(slab), ns, cx.stream)
-    _call('tg_slab_reduce_f32', _p(slab), ns, t, desc.ld_in, desc.c_out, c_dim, n_dim, _p(dst), cx.stream)
+    with cx.on_side(after_main=True):              # nothing on the main stream consumes dst before the phase's join
+        _call('tg_slab_reduce_f32', _p(slab), ns, t, desc.ld_in, desc.c_out, c_dim, n_dim, _p(dst), cx.stream)
 
 
 # ------------------------------------------------------------------ conv / dense (plain and weight-normalised)
@@ -90,12 +91,15 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     needs_w = cx.trains() and kernel_grad is not None
     needs_x = cx.tape is not None and x.requires_grad
     scale = None
-    if wn is not None:
-        scale = cx.scratch('wns', c_out)
-        _call('tg_wn_scale_f32', _p(kernel), _p(wn[0]), t * c_in, c_out, _p(scale), cx.stream)
-    w_oti = cx.scratch('woti', co_p * t * ci_p)
-    w_hwio = cx.scratch('whwio', t * ci_p * co_p) if needs_x else None
-    _call('tg_filter_prep_f32', _p(kernel), _p(scale), None, t, c_in, c_out, ci_p, co_p, _p(w_hwio), _p(w_oti), t * ci_p, ci_p, cx.stream)
+    with cx.on_side(forward=True):                 # weights are final since the phase's fork: runs ahead, beside the previous layer's launch
+        # (buffers written on the side stream are also ALLOCATED under it: a first-use zero fill is a launch on the current stream)
+        w_oti = cx.scratch('woti', co_p * t * ci_p)
+        w_hwio = cx.scratch('whwio', t * ci_p * co_p) if needs_x else None
+        if wn is not None:
+            scale = cx.scratch('wns', c_out)
+            _call('tg_wn_scale_f32', _p(kernel), _p(wn[0]), t * c_in, c_out, _p(scale), cx.stream)
+        _call('tg_filter_prep_f32', _p(kernel), _p(scale), None, t, c_in, c_out, ci_p, co_p, _p(w_hwio), _p(w_oti), t * ci_p, ci_p, cx.stream)
+    cx.main_waits_side()
     if n_store_ld is None:
         n_store, ld_out = c_out, co_p
     else:
@@ -163,8 +167,9 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
             else:
                 dw = cx.scratch('dw', t * c_in * c_out)
                 filter_grad(dw_desc, x.t, dpre, t, c_in, c_out, dw)
-                coef = cx.scratch('coef', 2 * c_out)
-                _call('tg_wn_bwd_f32', _p(dw), _p(kernel), _p(wn[0]), t * c_in, c_out, _p(kernel_grad), _p(wn[1]), _p(coef), cx.stream)
+                with cx.on_side():                 # behind the slab reduce, in side-stream order
+                    coef = cx.scratch('coef', 2 * c_out)
+                    _call('tg_wn_bwd_f32', _p(dw), _p(kernel), _p(wn[0]), t * c_in, c_out, _p(kernel_grad), _p(wn[1]), _p(coef), cx.stream)
         if needs_x:
             gx = cx.grad_of(x)
             dds = lib.desc_array(geom.conv_dgrad(x.n, x.h, x.w, ci_p, co_p, k, stride, padding, ld_out=gx.ld, n_store=ci_p))
@@ -184,12 +189,14 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
     needs_w = cx.trains() and kernel_grad is not None
     needs_x = cx.tape is not None and x.requires_grad
     scale_a = None
-    if wn is not None:
-        scale_a = cx.scratch('wnsa', c_out)
-        _call('tg_wn_scale_tab_f32', _p(kernel), _p(wn[0]), 25, c_out, c_in, _p(scale_a), cx.stream)
-    w_pad = cx.scratch('wpad', 25 * co_p * ci_p)
-    w_tr = cx.scratch('wtr', 25 * ci_p * co_p) if needs_x else None
-    _call('tg_filter_prep_f32', _p(kernel), None, _p(scale_a), 25, c_out, c_in, co_p, ci_p, _p(w_pad), _p(w_tr), co_p, ci_p * co_p, cx.stream)
+    with cx.on_side(forward=True):
+        w_pad = cx.scratch('wpad', 25 * co_p * ci_p)
+        w_tr = cx.scratch('wtr', 25 * ci_p * co_p) if needs_x else None
+        if wn is not None:
+            scale_a = cx.scratch('wnsa', c_out)
+            _call('tg_wn_scale_tab_f32', _p(kernel), _p(wn[0]), 25, c_out, c_in, _p(scale_a), cx.stream)
+        _call('tg_filter_prep_f32', _p(kernel), None, _p(scale_a), 25, c_out, c_in, co_p, ci_p, _p(w_pad), _p(w_tr), co_p, ci_p * co_p, cx.stream)
+    cx.main_waits_side()
     ld_out = c_out if narrow_out else co_p
     y = cx.new_act(x.n, 2 * x.h, 2 * x.w, c_out, ld_out, requires_grad=needs_w or needs_x)
     dds = lib.desc_array(geom.deconv_fwd(x.n, x.h, x.w, ci_p, co_p, ld_out=ld_out, n_store=c_out, act=act))
@@ -211,7 +218,8 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
             else:
                 dw = cx.scratch('dw', 25 * c_out * c_in)
                 filter_grad(geom.deconv_wgrad(x.n, x.h, x.w, co_p, ci_p), dpre, x.t, 25, c_out, c_in, dw)
-                _call('tg_wn_bwd_tab_f32', _p(dw), _p(kernel), _p(wn[0]), 25, c_out, c_in, _p(kernel_grad), _p(wn[1]), cx.stream)
+                with cx.on_side():
+                    _call('tg_wn_bwd_tab_f32', _p(dw), _p(kernel), _p(wn[0]), 25, c_out, c_in, _p(kernel_grad), _p(wn[1]), cx.stream)
         if needs_x:
             gx = cx.grad_of(x)
             _call('tg_igemm_f32', geom.deconv_dgrad(x.n, x.h, x.w, ci_p, co_p, ld_out=gx.ld, n_store=ci_p), _p(dpre), _p(w_tr), None,

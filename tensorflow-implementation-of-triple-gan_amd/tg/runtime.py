@@ -10,6 +10,7 @@ variable scopes and a Session there is ONE `Context` holding
 torch is used only as the device-buffer substrate (allocation, H2D copies, streams).
 """
 import contextlib
+import os
 import ctypes as C
 
 import numpy as np
@@ -193,6 +194,19 @@ class Context(object):
         # a dedicated non-default stream: hipStream capture is illegal on the legacy null stream
         self.torch_stream = torch.cuda.Stream(device=self.device)
         torch.cuda.set_stream(self.torch_stream)
+        # Optional side stream for the small dependent chains that are off the critical path (weight-norm scale + filter re-layouts
+        # ahead of a convolution; slab reduce + weight-norm gradient behind a filter-gradient launch), forked from / joined to the
+        # main stream by events inside every phase_scope so that a hipGraph capture records them as parallel branches.
+        # MEASURED NEGATIVE (round 1, MI355X, ROCm 7.2): 5 571 images/s without it, 5 386 with the backward chains only, 5 403 with
+        # both — a captured graph with cross-stream edges replays slower than the single chain even though ~1 ms of small launches
+        # become concurrent.  OFF by default; TG_SIDE_STREAM=1 (forward + backward) or 2 (backward only) re-enables it.
+        self.side_stream = torch.cuda.Stream(device=self.device)
+        mode = os.environ.get('TG_SIDE_STREAM', '0')
+        self.use_side_stream = mode != '0'
+        self.side_forward = mode == '1'
+        self._events = {}
+        self._side_depth = 0
+        self._phase_depth = 0          # the side stream is only used between a phase's fork and join
         self.buffers = {}
         self.stores = {}
         self.tape = None
@@ -210,6 +224,52 @@ class Context(object):
     @property
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _event(self, tag):
+        """one persistent event per call site (created in the first, eager iteration; reused inside captures)."""
+        self.counter += 1
+        key = '%s/%s%d' % (self.phase, tag, self.counter)
+        ev = self._events.get(key)
+        if ev is None:
+            ev = self._events[key] = torch.cuda.Event()
+        return ev
+
+    def _fork_side(self):
+        if self.use_side_stream:
+            ev = self._event('fork')
+            ev.record(self.torch_stream)
+            self.side_stream.wait_event(ev)
+
+    def _join_side(self):
+        if self.use_side_stream:
+            ev = self._event('join')
+            ev.record(self.side_stream)
+            self.torch_stream.wait_event(ev)
+
+    @contextlib.contextmanager
+    def on_side(self, after_main=False, forward=False):
+        """run the enclosed launches on the side stream (after_main: only after what the main stream has enqueued so far)."""
+        if not self.use_side_stream or self._side_depth or not self._phase_depth or (forward and not self.side_forward):
+            yield
+            return
+        if after_main:
+            ev = self._event('m2s')
+            ev.record(self.torch_stream)
+            self.side_stream.wait_event(ev)
+        self._side_depth += 1
+        torch.cuda.set_stream(self.side_stream)
+        try:
+            yield
+        finally:
+            torch.cuda.set_stream(self.torch_stream)
+            self._side_depth -= 1
+
+    def main_waits_side(self):
+        """the main stream continues only after what the side stream has enqueued so far."""
+        if self.use_side_stream and self.side_forward and not self._side_depth and self._phase_depth:
+            ev = self._event('s2m')
+            ev.record(self.side_stream)
+            self.torch_stream.wait_event(ev)
 
     # ---- workspace -------------------------------------------------------------------------------
     def ws(self, key, numel, zero=False):
@@ -265,9 +325,13 @@ class Context(object):
         self.phase, self.counter = name, counter
         self.tape = [] if record else None
         self.train_nets = set(train_nets)
+        self._fork_side()
+        self._phase_depth += 1
         try:
             yield self
         finally:
+            self._phase_depth -= 1
+            self._join_side()
             self.phase, self.counter, self.tape, self.train_nets = prev
 
     @contextlib.contextmanager
