@@ -119,6 +119,36 @@ __global__ void __launch_bounds__(256) slab_reduce(const float* __restrict__ sla
   }
 }
 
+// Few outputs, many slabs (the 3->128 first convolution: 3 456 outputs x 512 pixel splits): one thread per output would walk the
+// slabs serially with 14 workgroups on the chip.  Here 8 lanes share an output, each sums a contiguous range of slabs in order
+// and the 8 partial sums are combined in lane order — still one fixed summation order, bitwise reproducible.
+__global__ void __launch_bounds__(256) slab_reduce_wide(const float* __restrict__ slab, int n_split, int t_dim, int c_pad, int n_pad, int c_dim,
+                                                        int n_dim, float* __restrict__ dst) {
+  __shared__ float part[8][32];
+  const int64_t total = (int64_t)t_dim * c_dim * n_dim;
+  const int64_t sstride = (int64_t)t_dim * c_pad * n_pad;
+  const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + o;
+  float acc = 0.f;
+  if (i < total) {
+    const int n = (int)(i % n_dim);
+    const int64_t tc = i / n_dim;
+    const int c = (int)(tc % c_dim), t = (int)(tc / c_dim);
+    const float* p = slab + ((int64_t)t * c_pad + c) * n_pad + n;
+    const int per = (n_split + 7) / 8;
+    const int s0 = grp * per, s1 = min(n_split, s0 + per);
+    for (int s = s0; s < s1; ++s) acc += p[s * sstride];
+  }
+  part[grp][o] = acc;
+  __syncthreads();
+  if (grp == 0 && i < total) {
+    float r = part[0][o];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) r += part[g][o];
+    dst[i] = r;
+  }
+}
+
 // weight norm of a transposed-conv filter V[t][a][b] = [kh*kw][Cout][Cin]: the norm runs over axes (0,1,3) = (t, b) for
 // every output channel a (Model/modle_base.py:148).  One workgroup per output channel (Cout is 3 in the reference).
 __device__ float block_sum256(float v, float* red) {
@@ -197,7 +227,11 @@ int tg_slab_reduce_f32(const float* slab, int n_split, int t, int c_pad, int n_p
   TG_REQUIRE(slab && dst && n_split >= 1 && c <= c_pad && n <= n_pad, "slab_reduce: bad args");
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * t * c * n * (n_split + 1), s);
-  hipLaunchKernelGGL(slab_reduce, dim3(ew_grid((int64_t)t * c * n)), dim3(256), 0, s, slab, n_split, t, c_pad, n_pad, c, n, dst);
+  const int64_t total = (int64_t)t * c * n;
+  if (n_split >= 32 && total <= 65536)
+    hipLaunchKernelGGL(slab_reduce_wide, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, slab, n_split, t, c_pad, n_pad, c, n, dst);
+  else
+    hipLaunchKernelGGL(slab_reduce, dim3(ew_grid(total)), dim3(256), 0, s, slab, n_split, t, c_pad, n_pad, c, n, dst);
   TG_CHECK_LAUNCH("slab_reduce");
   return TG_OK;
 }

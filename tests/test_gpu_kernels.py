@@ -249,3 +249,20 @@ def test_fused_mean_only_batch_norm_forward_backward(prec):
              lib.ptr(sums), lib.ptr(dbd), st())
     np.testing.assert_allclose(dxd.cpu().numpy(), dx_ref, rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(dbd.cpu().numpy(), db_ref, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("n_split,t,c_pad,n_pad,c,n", [(512, 1, 32, 128, 27, 128), (56, 9, 128, 128, 128, 128), (3, 25, 64, 32, 42, 3), (40, 1, 32, 32, 5, 7)])
+def test_slab_reduce_both_paths(n_split, t, c_pad, n_pad, c, n):
+    """tg_slab_reduce_f32: dst[t][c][n] = sum over the pixel-split slabs, padding dropped; the few-outputs / many-slabs path
+    (first convolution, 512 splits) and the one-thread-per-output path; fixed summation order -> identical on repetition."""
+    lib = _lib()
+    rng = np.random.default_rng(11)
+    slab = rng.standard_normal((n_split, t, c_pad, n_pad)).astype(np.float32)
+    sd = dev(slab)
+    out = [torch.full((t * c * n,), 7.0, device='cuda') for _ in range(2)]
+    for o in out:
+        lib.call('tg_slab_reduce_f32', lib.ptr(sd), n_split, t, c_pad, n_pad, c, n, lib.ptr(o), st())
+    ref = slab[:, :, :c, :n].astype(np.float64).sum(0).reshape(-1)
+    got = out[0].cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(slab).sum(0).max()
+    assert torch.equal(out[0], out[1])
