@@ -92,7 +92,8 @@ int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const float* in, 
 
 /* tg_igemm_f32 (no bias, no activation) that also accumulates the per-(application segment, channel) sums of its output
  * into colsum[nseg][c_out] (fp64, zeroed by the call): the tf.nn.moments pass of mean_only_batch_norm_impl
- * (Model/nn.py:171-175) fused into the convolution.  seg_rows: HOST array, every entry a multiple of 32. */
+ * (Model/nn.py:171-175) fused into the convolution.  seg_rows: HOST array, at most 8 entries; a tile may straddle one
+ * application boundary, so every entry must be at least the row count of some tile that divides c_out (32 ... 128). */
 int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
                         double* colsum, void* stream);
 
@@ -168,8 +169,8 @@ int tg_mobn_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, i
 int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows, int nseg, const double* sums, const float* b, float* pop_mean,
                       float decay, int act, float alpha, void* stream);
 /* fused backward of mean-only BN + nonlinearity: dx = dy*act'(yact) - mean_seg(dy*act'(yact)), db[k] = sum over all rows
- * (db may be NULL).  sums: scratch of nseg*c doubles.  Two launches (sums with fp64 atomics, apply).  c <= 512, c % 4 == 0,
- * segment rows multiples of 32. */
+ * (db may be NULL).  sums: scratch of nseg*c doubles.  Two launches (sums with fp64 atomics, apply).  c <= 512, c % 4 == 0;
+ * segments of any size. */
 int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
                     int act, float alpha, double* sums, float* db, void* stream);
 /* shift[s][k] = -sums[s][k]/rows_s; db[k] = sum_s sums[s][k]. */

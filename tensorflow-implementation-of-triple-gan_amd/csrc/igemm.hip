@@ -306,27 +306,36 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     // Mean-only-BN variant: the pixel operand was the MFMA row operand, so a lane holds ONE output channel and its 16
     // registers hold rows — the tile's column sum is 16 adds + one cross-half shuffle per lane, accumulated with fp64
     // atomics into [segment][channel] (masked rows hold exact zeros; tiles never straddle a segment: launcher check).
+    // A tile may straddle ONE segment boundary (every segment has at least BM rows: launcher check): rows below `bnd` (tile-local)
+    // belong to segment `seg`, the others to seg + 1.
     int seg = 0, acc_rows = p.seg_rows[0];
     while (seg < p.nseg - 1 && m0 >= acc_rows) acc_rows += p.seg_rows[++seg];
+    const int bnd = acc_rows - m0;                        // >= 1; >= BM when the tile lies inside one segment
+    const bool two = bnd < BM && seg + 1 < p.nseg;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int n = n0 + wn0 + ni * 32 + col;
       const bool nok = n < d.n_store;
       const uint32_t ncol = nok ? (uint32_t)n * 4u : OOB_OFF;
-      float csum = 0.f;
+      float csum = 0.f, csum2 = 0.f;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float v = acc[mi][ni][r];
-          csum += v;
-          const uint32_t ro = t_ob[wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+          const int rl = wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (rl < bnd) csum += v; else csum2 += v;
+          const uint32_t ro = t_ob[rl];
           const uint32_t off = (ro | ncol) & OOB_OFF ? OOB_OFF : ro + ncol;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rsrc_o, off, 0, 0);
         }
       }
       csum += __shfl_xor(csum, 32, 64);
       if (half == 0 && nok) atomicAdd(p.colsum + (int64_t)seg * p.c_out + n, (double)csum);
+      if (two) {                                          // block-uniform
+        csum2 += __shfl_xor(csum2, 32, 64);
+        if (half == 0 && nok) atomicAdd(p.colsum + (int64_t)(seg + 1) * p.c_out + n, (double)csum2);
+      }
     }
     return;
   }
@@ -687,8 +696,8 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
   for (const Cand& c : cands) {
     if (d->c_out % c.bn) continue;
     if (force && (c.bm != fbm || c.bn != fbn)) continue;
-    bool seg_ok = true;                                      // COLSUM: a tile must not straddle two application segments
-    for (int i = 0; colsum && i < nseg; ++i) seg_ok = seg_ok && seg_rows[i] % c.bm == 0;
+    bool seg_ok = true;                                      // COLSUM: a tile may straddle at most one application boundary
+    for (int i = 0; colsum && i < nseg; ++i) seg_ok = seg_ok && seg_rows[i] >= c.bm;
     if (!seg_ok) continue;
     const int64_t per_sub = (int64_t)((p.M + c.bm - 1) / c.bm) * (d->c_out / c.bn);
     // K-tiles per CU: whole rounds for one problem; for the unequal sub-problems of a stride-2 launch (4/6/6/9 taps of a 5x5
@@ -740,7 +749,7 @@ static int igemm_colsum_impl(const tg_igemm_desc* d, const float* in, const floa
   TG_REQUIRE(d && colsum && seg_rows && nseg >= 1 && nseg <= 8, "igemm_colsum: bad args");
   TG_REQUIRE(d->act == TG_ACT_NONE, "igemm_colsum: the statistics are of the raw convolution output (no activation)");
   int tot = 0;
-  for (int i = 0; i < nseg; ++i) { TG_REQUIRE(seg_rows[i] > 0 && seg_rows[i] % 32 == 0, "igemm_colsum: segment %d has %d rows (need a multiple of 32)", i, seg_rows[i]); tot += seg_rows[i]; }
+  for (int i = 0; i < nseg; ++i) { TG_REQUIRE(seg_rows[i] >= 32, "igemm_colsum: segment %d has %d rows (need at least one 32-row tile)", i, seg_rows[i]); tot += seg_rows[i]; }
   TG_REQUIRE(tot == d->n_img * d->h_v * d->w_v, "igemm_colsum: segments sum to %d rows, launch has %d", tot, d->n_img * d->h_v * d->w_v);
   hipError_t e = hipMemsetAsync(colsum, 0, sizeof(double) * nseg * d->c_out, tg::as_stream(stream));
   if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(colsum)");

@@ -24,6 +24,23 @@ __device__ __forceinline__ int seg_of_row(const SegTable& st, int r, int* row_in
   return st.nseg - 1;
 }
 
+// Row chunks enumerated segment by segment: workgroup `bid` gets rows [r0, r1) of ONE segment, whatever the segment sizes.
+__device__ __forceinline__ bool bn_chunk(const SegTable& st, int chunk, int bid, int* seg, int* r0, int* r1) {
+  int base = 0;
+  for (int s = 0; s < st.nseg; ++s) {
+    const int n = (st.rows[s] + chunk - 1) / chunk;
+    if (bid < n) {
+      *seg = s;
+      *r0 = base + bid * chunk;
+      *r1 = min(base + st.rows[s], *r0 + chunk);
+      return true;
+    }
+    bid -= n;
+    base += st.rows[s];
+  }
+  return false;
+}
+
 // mode: 0 SUM(a) ; 1 SUM(a), SUM(a^2) ; 2 SUM(a*act'(b)) ; 3 SUM(a), SUM(a*b) ;
 // 4 SUM((a-mu)^2) with mu[c] = b[c]*alpha (b = per-channel sums of a previous mode-0 pass, alpha = 1/rows)
 struct d4 { double x, y, z, w; };
@@ -205,9 +222,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply(const float* __restrict__ dy
 __global__ void __launch_bounds__(256) mobn_apply(float* __restrict__ x, int ld, int rows, int c, SegTable st, const double* __restrict__ sums,
                                                   const float* __restrict__ b, float* __restrict__ pop, float decay, int act, float alpha) {
   __shared__ float shift[512];
-  const int r0 = blockIdx.x * 32;
-  int sb;
-  const int seg = seg_of_row(st, r0, &sb);
+  int seg, r0, r1;
+  if (!bn_chunk(st, 32, blockIdx.x, &seg, &r0, &r1)) return;
   for (int k = threadIdx.x; k < c; k += 256) {
     const float bb = b ? b[k] : 0.f;
     shift[k] = sums ? bb - (float)(sums[(int64_t)seg * c + k] / (double)st.rows[seg]) : bb - pop[k];
@@ -221,7 +237,7 @@ __global__ void __launch_bounds__(256) mobn_apply(float* __restrict__ x, int ld,
   }
   __syncthreads();
   const int c4 = c >> 2;
-  const int rows_here = min(32, rows - r0);
+  const int rows_here = r1 - r0;
   for (int i = threadIdx.x; i < rows_here * c4; i += 256) {
     const int rr = i / c4, cg = i - rr * c4;
     float4* p = reinterpret_cast<float4*>(x + (int64_t)(r0 + rr) * ld + cg * 4);
@@ -237,46 +253,33 @@ __global__ void __launch_bounds__(256) mobn_apply(float* __restrict__ x, int ld,
 // Mean-only-BN backward in two launches: (1) sums[seg][c] += sum_rows dy*act'(y) (one fp64 atomic per column per workgroup),
 // (2) dpre = dy*act'(y) - sums[seg]/rows_seg with the shift derived in LDS; workgroup 0 writes db = sum_seg sums.
 __global__ void __launch_bounds__(256) mobn_bwd_sums(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y, int rows, int c,
-                                                     SegTable st, int act, float alpha, double* __restrict__ sums, int units_per_block) {
-  // each workgroup walks units_per_block 32-row units; partial column sums are flushed (one fp64 atomic per column) when the
-  // segment changes and at the end.
+                                                     SegTable st, int act, float alpha, double* __restrict__ sums, int chunk) {
+  // each workgroup walks `chunk` rows of one segment (a few hundred workgroups in all: the atomics on the nseg*c accumulators
+  // serialise, 9 600 32-row workgroups were slower than the two-stage reduction this replaces)
+  int seg, r0, r1;
+  if (!bn_chunk(st, chunk, blockIdx.x, &seg, &r0, &r1)) return;
   const int c4 = c >> 2;
   const int lanes = 256 / c4 > 0 ? 256 / c4 : 1;
   const int cg = threadIdx.x % c4, rl = threadIdx.x / c4;
-  const int units = (rows + 31) >> 5;
-  const int u0 = blockIdx.x * units_per_block, u1 = min(units, u0 + units_per_block);
   __shared__ float4 red[256];
   float4 acc = {0, 0, 0, 0};
-  int cur_seg = -1;
-  for (int u = u0; u <= u1; ++u) {
-    int sb, seg = -2;
-    if (u < u1) seg = seg_of_row(st, u * 32, &sb);
-    if (seg != cur_seg) {
-      if (cur_seg >= 0) {
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        if (rl == 0) {
-          for (int k = 1; k < lanes; ++k) {
-            const float4 t = red[k * c4 + cg];
-            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-          }
-          double* o = sums + (int64_t)cur_seg * c + cg * 4;
-          atomicAdd(o, (double)acc.x); atomicAdd(o + 1, (double)acc.y); atomicAdd(o + 2, (double)acc.z); atomicAdd(o + 3, (double)acc.w);
-        }
-        __syncthreads();
-        acc = {0, 0, 0, 0};
-      }
-      cur_seg = seg;
+  if (rl < lanes) {
+    for (int r = r0 + rl; r < r1; r += lanes) {
+      const float4 g = *reinterpret_cast<const float4*>(dy + (int64_t)r * ld_dy + cg * 4);
+      const float4 yy = *reinterpret_cast<const float4*>(y + (int64_t)r * ld_y + cg * 4);
+      acc.x += g.x * tgd::act_grad(yy.x, act, alpha); acc.y += g.y * tgd::act_grad(yy.y, act, alpha);
+      acc.z += g.z * tgd::act_grad(yy.z, act, alpha); acc.w += g.w * tgd::act_grad(yy.w, act, alpha);
     }
-    if (u < u1 && rl < lanes) {
-      const int r0 = u * 32, rows_here = min(32, rows - r0);
-      for (int rr = rl; rr < rows_here; rr += lanes) {
-        const float4 g = *reinterpret_cast<const float4*>(dy + (int64_t)(r0 + rr) * ld_dy + cg * 4);
-        const float4 yy = *reinterpret_cast<const float4*>(y + (int64_t)(r0 + rr) * ld_y + cg * 4);
-        acc.x += g.x * tgd::act_grad(yy.x, act, alpha); acc.y += g.y * tgd::act_grad(yy.y, act, alpha);
-        acc.z += g.z * tgd::act_grad(yy.z, act, alpha); acc.w += g.w * tgd::act_grad(yy.w, act, alpha);
-      }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < lanes; ++k) {
+      const float4 t = red[k * c4 + cg];
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
     }
+    double* o = sums + (int64_t)seg * c + cg * 4;
+    atomicAdd(o, (double)acc.x); atomicAdd(o + 1, (double)acc.y); atomicAdd(o + 2, (double)acc.z); atomicAdd(o + 3, (double)acc.w);
   }
 }
 
@@ -284,9 +287,8 @@ __global__ void __launch_bounds__(256) mobn_bwd_apply(const float* __restrict__ 
                                                       float* __restrict__ dx, int ld_dx, int rows, int c, SegTable st, int act, float alpha,
                                                       const double* __restrict__ sums, float* __restrict__ db) {
   __shared__ float shift[512];
-  const int r0 = blockIdx.x * 32;
-  int sb;
-  const int seg = seg_of_row(st, r0, &sb);
+  int seg, r0, r1;
+  if (!bn_chunk(st, 32, blockIdx.x, &seg, &r0, &r1)) return;
   for (int k = threadIdx.x; k < c; k += 256) shift[k] = -(float)(sums[(int64_t)seg * c + k] / (double)st.rows[seg]);
   if (blockIdx.x == 0 && db) {
     for (int k = threadIdx.x; k < c; k += 256) {
@@ -297,7 +299,7 @@ __global__ void __launch_bounds__(256) mobn_bwd_apply(const float* __restrict__ 
   }
   __syncthreads();
   const int c4 = c >> 2;
-  const int rows_here = min(32, rows - r0);
+  const int rows_here = r1 - r0;
   for (int i = threadIdx.x; i < rows_here * c4; i += 256) {
     const int rr = i / c4, cg = i - rr * c4;
     const float4 g = *reinterpret_cast<const float4*>(dy + (int64_t)(r0 + rr) * ld_dy + cg * 4);
@@ -399,22 +401,6 @@ __global__ void bn_bwd_finalize(const float* __restrict__ s_dy, const float* __r
 // Work decomposition: blockIdx.x enumerates row chunks segment by segment (a chunk never straddles two segments, whatever
 // their sizes), blockIdx.y column blocks of BN_CW columns.
 constexpr int BN_CW = 256;
-
-__device__ __forceinline__ bool bn_chunk(const SegTable& st, int chunk, int bid, int* seg, int* r0, int* r1) {
-  int base = 0;
-  for (int s = 0; s < st.nseg; ++s) {
-    const int n = (st.rows[s] + chunk - 1) / chunk;
-    if (bid < n) {
-      *seg = s;
-      *r0 = base + bid * chunk;
-      *r1 = min(base + st.rows[s], *r0 + chunk);
-      return true;
-    }
-    bid -= n;
-    base += st.rows[s];
-  }
-  return false;
-}
 
 template <bool BWD>
 __global__ void __launch_bounds__(256) bn_sums(const float* __restrict__ a, int ld_a, const float* __restrict__ b, int ld_b, int c, SegTable st,
@@ -691,16 +677,21 @@ int tg_mobn_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, i
   return TG_OK;
 }
 
+static int seg_chunks(const SegTable& st, int chunk) {
+  int n = 0;
+  for (int s = 0; s < st.nseg; ++s) n += (st.rows[s] + chunk - 1) / chunk;
+  return n;
+}
+
 int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows, int nseg, const double* sums, const float* b, float* pop_mean,
                       float decay, int act, float alpha, void* stream) {
   SegTable st;
   int rc = make_segs(st, seg_rows, nseg, rows);
   if (rc != TG_OK) return rc;
   TG_REQUIRE(x && pop_mean && c > 0 && c <= 512 && c % 4 == 0 && ld % 4 == 0 && c <= ld, "mobn_apply: c=%d ld=%d unsupported", c, ld);
-  for (int i = 0; i < nseg; ++i) TG_REQUIRE(seg_rows[i] % 32 == 0 || nseg == 1, "mobn_apply: segment %d has %d rows (need a multiple of 32)", i, seg_rows[i]);
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_NORM, 0, 8.0 * rows * c, s);
-  hipLaunchKernelGGL(mobn_apply, dim3((rows + 31) / 32), dim3(256), 0, s, x, ld, rows, c, st, sums, b, pop_mean, decay, act, alpha);
+  hipLaunchKernelGGL(mobn_apply, dim3(seg_chunks(st, 32)), dim3(256), 0, s, x, ld, rows, c, st, sums, b, pop_mean, decay, act, alpha);
   TG_CHECK_LAUNCH("mobn_apply");
   return TG_OK;
 }
@@ -713,16 +704,14 @@ int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, flo
   TG_REQUIRE(dy && yact && dx && sums, "mobn_bwd: null buffer");
   TG_REQUIRE(c > 0 && c <= 512 && c % 4 == 0 && ld_dy % 4 == 0 && ld_y % 4 == 0 && ld_dx % 4 == 0 && c <= ld_dy && c <= ld_y && c <= ld_dx,
              "mobn_bwd: c=%d vs ld unsupported", c);
-  for (int i = 0; i < nseg; ++i) TG_REQUIRE(seg_rows[i] % 32 == 0 || nseg == 1, "mobn_bwd: segment %d has %d rows (need a multiple of 32)", i, seg_rows[i]);
   hipStream_t s = tg::as_stream(stream);
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * nseg * c, s);
   if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(mobn_bwd sums)");
   tg::ProfScope prof(tg::PC_NORM, 0, 20.0 * rows * c, s);
-  const int blocks = (rows + 31) / 32;
-  const int upb = (blocks + 767) / 768;
-  hipLaunchKernelGGL(mobn_bwd_sums, dim3((blocks + upb - 1) / upb), dim3(256), 0, s, dy, ld_dy, yact, ld_y, rows, c, st, act, alpha, sums, upb);
+  const int chunk = ((rows + 767) / 768 + 31) / 32 * 32;        // <= ~768 workgroups (+ one per segment)
+  hipLaunchKernelGGL(mobn_bwd_sums, dim3(seg_chunks(st, chunk)), dim3(256), 0, s, dy, ld_dy, yact, ld_y, rows, c, st, act, alpha, sums, chunk);
   TG_CHECK_LAUNCH("mobn_bwd_sums");
-  hipLaunchKernelGGL(mobn_bwd_apply, dim3(blocks), dim3(256), 0, s, dy, ld_dy, yact, ld_y, dx, ld_dx, rows, c, st, act, alpha, sums, db);
+  hipLaunchKernelGGL(mobn_bwd_apply, dim3(seg_chunks(st, 32)), dim3(256), 0, s, dy, ld_dy, yact, ld_y, dx, ld_dx, rows, c, st, act, alpha, sums, db);
   TG_CHECK_LAUNCH("mobn_bwd_apply");
   return TG_OK;
 }

@@ -52,8 +52,9 @@ _IGEMM_TILES = ((128, 128), (64, 128), (64, 64), (128, 64), (32, 128), (128, 32)
 
 
 def _colsum_tile_exists(c_out, seg_rows):
-    """tg_igemm_colsum_* needs a tile whose rows never straddle two application segments (and at most 8 segments)."""
-    return len(seg_rows) <= 8 and any(c_out % bn == 0 and all(r % bm == 0 for r in seg_rows) for bm, bn in _IGEMM_TILES)
+    """tg_igemm_colsum_* needs a tile that straddles at most one application boundary: every segment at least as long as
+    the tile (and at most 8 segments)."""
+    return len(seg_rows) <= 8 and any(c_out % bn == 0 and all(r >= bm for r in seg_rows) for bm, bn in _IGEMM_TILES)
 
 
 def wgrad_splits(desc, m):
@@ -143,7 +144,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
             dpre = cx.scratch('dpre', y.rows * co_p)
         if mobn is None and dpre is gy.t:
             pass
-        elif mobn is not None and c_out == co_p and c_out <= 512 and all(r % 32 == 0 for r in seg_rows):
+        elif mobn is not None and c_out == co_p and c_out <= 512 and len(seg_rows) <= 8:
             db = mobn[1] if needs_w else cx.scratch('db', c_out)
             sums64 = cx.scratch('bs64', 2 * len(seg_rows) * c_out)
             _call('tg_mobn_bwd_f32', gy.ptr, gy.ld, y.ptr, y.ld, _p(dpre), co_p, y.rows, c_out, seg_array(seg_rows), len(seg_rows),

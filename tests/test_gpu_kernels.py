@@ -190,15 +190,16 @@ def test_philox_streams_are_distinct_and_well_distributed():
     assert (o.sum(1) == 1).all() and o.sum(0).min() > 50
 
 
+@pytest.mark.parametrize("segs,h", [([2, 4, 1], 8), ([5, 5, 9], 6)])      # 64-pixel images (aligned) and 36-pixel ones (ragged: tiles straddle applications)
 @pytest.mark.parametrize("prec", ['f32', 'bf16'])
-def test_fused_mean_only_batch_norm_forward_backward(prec):
+def test_fused_mean_only_batch_norm_forward_backward(prec, segs, h):
     """tg_igemm_colsum_{f32,bf16} + tg_mobn_apply_f32 (training and evaluation) and tg_mobn_bwd_f32 against the oracle's
     conv2d + mean_only_batch_norm (Model/nn.py:147-187) applied per application segment, pop_mean updated sequentially."""
     from tg import geom
     lib = _lib()
     q = (lambda a: T.bf16_round(a)) if prec == 'bf16' else (lambda a: a)
     rng = np.random.default_rng(5)
-    segs, h, w, cin, cout = [2, 4, 1], 8, 8, 64, 128
+    w, cin, cout = h, 64, 128
     n = sum(segs)
     x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
     wt = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
