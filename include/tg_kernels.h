@@ -91,11 +91,12 @@ int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const float* in, 
                        void* stream);
 
 /* tg_igemm_f32 (no bias, no activation) that also accumulates the per-(application segment, channel) sums of its output
- * into colsum[nseg][c_out] (fp64, zeroed by the call): the tf.nn.moments pass of mean_only_batch_norm_impl
+ * into colsum[nseg][c_out] (fp64; zeroed by the call unless colsum_zeroed != 0 — the caller then guarantees zeros, e.g. one
+ * memset over an arena holding the accumulators of a whole solver run instead of one memset per layer): the tf.nn.moments pass of mean_only_batch_norm_impl
  * (Model/nn.py:171-175) fused into the convolution.  seg_rows: HOST array, at most 8 entries; a tile may straddle one
  * application boundary, so every entry must be at least the row count of some tile that divides c_out (32 ... 128). */
 int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
-                        double* colsum, void* stream);
+                        double* colsum, int colsum_zeroed, void* stream);
 
 /* filter gradient, split over `n_split` pixel ranges:
  * slab[s][t][c][n] = sum_{p in split s} in[pix(p,t),c] * dout[p,n]   (c < ld_in, n < c_out).
@@ -112,7 +113,7 @@ int tg_igemm_bf16(const tg_igemm_desc* d, const float* in, const float* w, const
 int tg_igemm_multi_bf16(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,
                         void* stream);
 int tg_igemm_colsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
-                         double* colsum, void* stream);
+                         double* colsum, int colsum_zeroed, void* stream);
 int tg_wgrad_bf16(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream);
 
 /* ---- parameter-side kernels ---------------------------------------------------------------------- */
@@ -169,10 +170,10 @@ int tg_mobn_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, i
 int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows, int nseg, const double* sums, const float* b, float* pop_mean,
                       float decay, int act, float alpha, void* stream);
 /* fused backward of mean-only BN + nonlinearity: dx = dy*act'(yact) - mean_seg(dy*act'(yact)), db[k] = sum over all rows
- * (db may be NULL).  sums: scratch of nseg*c doubles.  Two launches (sums with fp64 atomics, apply).  c <= 512, c % 4 == 0;
+ * (db may be NULL).  sums: scratch of nseg*c doubles (sums_zeroed as colsum_zeroed above).  Two launches (sums with fp64 atomics, apply).  c <= 512, c % 4 == 0;
  * segments of any size. */
 int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
-                    int act, float alpha, double* sums, float* db, void* stream);
+                    int act, float alpha, double* sums, int sums_zeroed, float* db, void* stream);
 /* shift[s][k] = -sums[s][k]/rows_s; db[k] = sum_s sums[s][k]. */
 int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, int rows, int c, float* shift, float* db, void* stream);
 /* Fused training-mode batch norm over application segments (two launches): per segment s and column k
@@ -181,11 +182,13 @@ int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nse
  * are updated sequentially over the segments with the unbiased variance.  sums: scratch of 2*nseg*c doubles.  c need not be a
  * multiple of 4 (columns up to the next multiple of 4 are read and written; they must lie inside ld). */
 int tg_bn_train_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int c, const int32_t* seg_rows, int nseg, const float* gamma,
-                    const float* beta, float eps, float decay, float* moving_mean, float* moving_var, double* sums, float* mean_inv, void* stream);
+                    const float* beta, float eps, float decay, float* moving_mean, float* moving_var, double* sums, int sums_zeroed, float* mean_inv,
+                    void* stream);
 /* its backward: dx = gamma*inv*(dy - mean_s(dy) - xhat*mean_s(dy*xhat)) per segment (masked by x > 0 when relu_input: the gradient is
  * then with respect to the pre-ReLU value), dgamma = sum_s sum dy*xhat, dbeta = sum_s sum dy (both NULL: not wanted). */
 int tg_bn_train_bwd_f32(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
-                        const float* gamma, const float* mean_inv, int relu_input, double* sums, float* dgamma, float* dbeta, void* stream);
+                        const float* gamma, const float* mean_inv, int relu_input, double* sums, int sums_zeroed, float* dgamma, float* dbeta,
+                        void* stream);
 /* batch norm (training mode, biased variance) from s1 = sum x and s2 = sum (x-mean)^2 (modes 0 and 4 above):
  * scale = gamma*inv, shift = beta - mean*scale, mean_inv = [mean | inv];
  * moving statistics updated in place when non-NULL (bessel = use the unbiased variance, the fused 4-D kernel). */

@@ -745,25 +745,27 @@ extern "C" int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float
 }
 
 static int igemm_colsum_impl(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
-                             double* colsum, void* stream, bool bf16) {
+                             double* colsum, int colsum_zeroed, void* stream, bool bf16) {
   TG_REQUIRE(d && colsum && seg_rows && nseg >= 1 && nseg <= 8, "igemm_colsum: bad args");
   TG_REQUIRE(d->act == TG_ACT_NONE, "igemm_colsum: the statistics are of the raw convolution output (no activation)");
   int tot = 0;
   for (int i = 0; i < nseg; ++i) { TG_REQUIRE(seg_rows[i] >= 32, "igemm_colsum: segment %d has %d rows (need at least one 32-row tile)", i, seg_rows[i]); tot += seg_rows[i]; }
   TG_REQUIRE(tot == d->n_img * d->h_v * d->w_v, "igemm_colsum: segments sum to %d rows, launch has %d", tot, d->n_img * d->h_v * d->w_v);
-  hipError_t e = hipMemsetAsync(colsum, 0, sizeof(double) * nseg * d->c_out, tg::as_stream(stream));
-  if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(colsum)");
+  if (!colsum_zeroed) {
+    hipError_t e = hipMemsetAsync(colsum, 0, sizeof(double) * nseg * d->c_out, tg::as_stream(stream));
+    if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(colsum)");
+  }
   return igemm_impl(d, 1, in, w, nullptr, out, stream, colsum, seg_rows, nseg, bf16);
 }
 
 extern "C" int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
-                                   double* colsum, void* stream) {
-  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, stream, false);
+                                   double* colsum, int colsum_zeroed, void* stream) {
+  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, false);
 }
 
 extern "C" int tg_igemm_colsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
-                                    double* colsum, void* stream) {
-  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, stream, true);
+                                    double* colsum, int colsum_zeroed, void* stream) {
+  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, true);
 }
 
 extern "C" int tg_igemm_multi_bf16(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,

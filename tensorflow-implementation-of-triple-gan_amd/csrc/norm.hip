@@ -707,7 +707,7 @@ int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows
 }
 
 int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
-                    int act, float alpha, double* sums, float* db, void* stream) {
+                    int act, float alpha, double* sums, int sums_zeroed, float* db, void* stream) {
   SegTable st;
   int rc = make_segs(st, seg_rows, nseg, rows);
   if (rc != TG_OK) return rc;
@@ -715,8 +715,10 @@ int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, flo
   TG_REQUIRE(c > 0 && c <= 512 && c % 4 == 0 && ld_dy % 4 == 0 && ld_y % 4 == 0 && ld_dx % 4 == 0 && c <= ld_dy && c <= ld_y && c <= ld_dx,
              "mobn_bwd: c=%d vs ld unsupported", c);
   hipStream_t s = tg::as_stream(stream);
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * nseg * c, s);
-  if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(mobn_bwd sums)");
+  if (!sums_zeroed) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * nseg * c, s);
+    if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(mobn_bwd sums)");
+  }
   tg::ProfScope prof(tg::PC_NORM, 0, 20.0 * rows * c, s);
   const int chunk = stats_chunk(st);                             // <= 128 workgroups per segment (atomic tail, see stats_chunk)
   hipLaunchKernelGGL(mobn_bwd_sums, dim3(seg_chunks(st, chunk)), dim3(256), 0, s, dy, ld_dy, yact, ld_y, rows, c, st, act, alpha, sums, chunk);
@@ -748,7 +750,8 @@ static int bn_grid(const SegTable& st, int rows, int c, int* chunk, dim3* grid) 
 }
 
 int tg_bn_train_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int c, const int32_t* seg_rows, int nseg, const float* gamma,
-                    const float* beta, float eps, float decay, float* moving_mean, float* moving_var, double* sums, float* mean_inv, void* stream) {
+                    const float* beta, float eps, float decay, float* moving_mean, float* moving_var, double* sums, int sums_zeroed, float* mean_inv,
+                    void* stream) {
   SegTable st;
   int rc = make_segs(st, seg_rows, nseg, rows);
   if (rc != TG_OK) return rc;
@@ -756,8 +759,10 @@ int tg_bn_train_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int 
   TG_REQUIRE(c > 0 && ld_x % 4 == 0 && ld_y % 4 == 0 && (c + 3) / 4 * 4 <= ld_x && (c + 3) / 4 * 4 <= ld_y, "bn_train: c=%d vs ld=%d/%d", c, ld_x, ld_y);
   TG_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_train: moving_mean / moving_var must both be given or both be NULL");
   hipStream_t s = tg::as_stream(stream);
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * nseg * c, s);
-  if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn sums)");
+  if (!sums_zeroed) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * nseg * c, s);
+    if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn sums)");
+  }
   tg::ProfScope prof(tg::PC_NORM, 0, 12.0 * rows * c, s);
   int chunk; dim3 grid;
   bn_grid(st, rows, c, &chunk, &grid);
@@ -769,7 +774,8 @@ int tg_bn_train_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int 
 }
 
 int tg_bn_train_bwd_f32(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
-                        const float* gamma, const float* mean_inv, int relu_input, double* sums, float* dgamma, float* dbeta, void* stream) {
+                        const float* gamma, const float* mean_inv, int relu_input, double* sums, int sums_zeroed, float* dgamma, float* dbeta,
+                        void* stream) {
   SegTable st;
   int rc = make_segs(st, seg_rows, nseg, rows);
   if (rc != TG_OK) return rc;
@@ -778,8 +784,10 @@ int tg_bn_train_bwd_f32(const float* dy, int ld_dy, const float* x, int ld_x, fl
   const int cp = (c + 3) / 4 * 4;
   TG_REQUIRE(c > 0 && ld_dy % 4 == 0 && ld_x % 4 == 0 && ld_dx % 4 == 0 && cp <= ld_dy && cp <= ld_x && cp <= ld_dx, "bn_train_bwd: c=%d vs ld", c);
   hipStream_t s = tg::as_stream(stream);
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * nseg * c, s);
-  if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn bwd sums)");
+  if (!sums_zeroed) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * nseg * c, s);
+    if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn bwd sums)");
+  }
   tg::ProfScope prof(tg::PC_NORM, 0, 20.0 * rows * c, s);
   int chunk; dim3 grid;
   bn_grid(st, rows, c, &chunk, &grid);

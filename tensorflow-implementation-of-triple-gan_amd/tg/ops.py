@@ -113,8 +113,8 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     if fused:
         # convolution + per-(application, channel) sums in one launch, then one fused apply pass (mean, +b, activation, pop_mean)
         b, b_grad, pop = mobn
-        sums = cx.scratch('cs64', 2 * len(seg_rows) * c_out)          # fp64 accumulators
-        _call('tg_igemm_colsum_f32', d, x.ptr, _p(w_oti), y.ptr, seg_array(seg_rows), len(seg_rows), _p(sums), cx.stream)
+        sums, zd = cx.zscratch('cs64', 2 * len(seg_rows) * c_out)     # fp64 accumulators
+        _call('tg_igemm_colsum_f32', d, x.ptr, _p(w_oti), y.ptr, seg_array(seg_rows), len(seg_rows), _p(sums), zd, cx.stream)
         _call('tg_mobn_apply_f32', y.ptr, y.ld, y.rows, c_out, seg_array(seg_rows), len(seg_rows), _p(sums), _p(b), _p(pop), 0.9, ACT[act],
               alpha, cx.stream)
     else:
@@ -146,9 +146,9 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
             pass
         elif mobn is not None and c_out == co_p and c_out <= 512 and len(seg_rows) <= 8:
             db = mobn[1] if needs_w else cx.scratch('db', c_out)
-            sums64 = cx.scratch('bs64', 2 * len(seg_rows) * c_out)
+            sums64, zd = cx.zscratch('bs64', 2 * len(seg_rows) * c_out)
             _call('tg_mobn_bwd_f32', gy.ptr, gy.ld, y.ptr, y.ld, _p(dpre), co_p, y.rows, c_out, seg_array(seg_rows), len(seg_rows),
-                  ACT[act], alpha, _p(sums64), _p(db), cx.stream)
+                  ACT[act], alpha, _p(sums64), zd, _p(db), cx.stream)
         elif mobn is not None:
             sums, _ = colstats(2, gy.t, gy.ld, y.t, y.ld, y.rows, c_out, seg_rows, act, alpha)
             sh = cx.scratch('bshift', len(seg_rows) * c_out)
@@ -256,11 +256,11 @@ def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_g
     needs = cx.tape is not None and (x.requires_grad or trains)
     seg_rows = _segs(x, segments)
     nseg = len(seg_rows)
-    sums = cx.scratch('bn64', 4 * nseg * c)                   # 2*nseg*c doubles
+    sums, zd = cx.zscratch('bn64', 4 * nseg * c)              # 2*nseg*c doubles
     mean_inv = cx.scratch('bnmi', 2 * nseg * c)
     y = cx.new_act(x.n, x.h, x.w, c, x.ld, requires_grad=needs)
     _call('tg_bn_train_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, seg_array(seg_rows), nseg, _p(gamma), _p(beta), eps, decay, _p(mm), _p(mv),
-          _p(sums), _p(mean_inv), cx.stream)
+          _p(sums), zd, _p(mean_inv), cx.stream)
     if not needs:
         return y
 
@@ -269,9 +269,9 @@ def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_g
         assert gy is not None
         want = trains and gamma_grad is not None
         gx = cx.grad_of(x)
-        bsums = cx.scratch('bnb64', 4 * nseg * c)
+        bsums, zdb = cx.zscratch('bnb64', 4 * nseg * c)
         _call('tg_bn_train_bwd_f32', gy.ptr, gy.ld, x.ptr, x.ld, gx.ptr, gx.ld, x.rows, c, seg_array(seg_rows), nseg, _p(gamma), _p(mean_inv),
-              1 if relu_input else 0, _p(bsums), _p(gamma_grad) if want else None, _p(beta_grad) if want else None, cx.stream)
+              1 if relu_input else 0, _p(bsums), zdb, _p(gamma_grad) if want else None, _p(beta_grad) if want else None, cx.stream)
 
     cx.record(bwd)
     return y

@@ -204,6 +204,9 @@ class Context(object):
         mode = os.environ.get('TG_SIDE_STREAM', '0')
         self.use_side_stream = mode != '0'
         self.side_forward = mode == '1'
+        # fp64 statistics accumulators (fused mean-only BN / batch norm) of one solver run live in ONE arena per phase, zeroed by one
+        # launch at the start of the phase instead of one memset per layer and direction (36 -> 3 launches per iteration)
+        self._zarena = {}              # phase -> dict(sizes=[...], buf=tensor or None, cursor=int, recording=bool)
         self._events = {}
         self._side_depth = 0
         self._phase_depth = 0          # the side stream is only used between a phase's fork and join
@@ -291,6 +294,39 @@ class Context(object):
         self.counter += 1
         return self.ws('%s/%s%d' % (self.phase, tag, self.counter), numel)
 
+    def zscratch(self, tag, numel):
+        """(tensor, zeroed) for a statistics accumulator of `numel` floats (= numel/2 doubles).  The first time a phase runs the
+        requests are recorded and served as ordinary scratch (zeroed = 0: the kernel clears it); from then on they are slices of the
+        phase's arena, cleared by _zarena_begin (zeroed = 1)."""
+        numel = (int(numel) + 63) // 64 * 64
+        za = self._zarena.setdefault(self.phase, dict(sizes=[], buf=None, cursor=0, off=0, recording=True))
+        if za['recording'] or za['buf'] is None:
+            if za['recording']:
+                za['sizes'].append(numel)
+            return self.scratch(tag, numel), 0
+        k = za['cursor']
+        if k >= len(za['sizes']) or za['sizes'][k] != numel:          # a different op sequence than recorded: stay correct
+            za['cursor'] = len(za['sizes']) + 1
+            return self.scratch(tag, numel), 0
+        t = za['buf'][za['off']:za['off'] + numel]
+        za['cursor'], za['off'] = k + 1, za['off'] + numel
+        self.counter += 1                                              # keep the call-site numbering of the recording pass
+        return t, 1
+
+    def _zarena_begin(self, resume):
+        za = self._zarena.get(self.phase)
+        if za is None or za['recording'] or resume or za['buf'] is None:
+            return
+        za['cursor'], za['off'] = 0, 0
+        lib.call('tg_fill_f32', lib.ptr(za['buf']), 0.0, za['buf'].numel(), self.stream)
+
+    def _zarena_end(self):
+        za = self._zarena.get(self.phase)
+        if za is not None and za['recording']:
+            za['recording'] = False
+            if za['sizes']:                 # allocated here, in the eager recording pass — never inside a stream capture
+                za['buf'] = torch.zeros(sum(za['sizes']), dtype=torch.float32, device=self.device)
+
     def grad_of(self, a):
         """gradient buffer of an activation (same layout), allocated on first use per call site."""
         if a.grad is None:
@@ -327,9 +363,11 @@ class Context(object):
         self.train_nets = set(train_nets)
         self._fork_side()
         self._phase_depth += 1
+        self._zarena_begin(resume=counter != 0)
         try:
             yield self
         finally:
+            self._zarena_end()
             self._phase_depth -= 1
             self._join_side()
             self.phase, self.counter, self.tape, self.train_nets = prev

@@ -222,7 +222,7 @@ def test_fused_mean_only_batch_norm_forward_backward(prec, segs, h):
     yd = torch.full((n, h, w, cout), 7.0, device='cuda')
     sums = torch.zeros(2 * len(segs) * cout, device='cuda')          # nseg*c doubles
     d = geom.conv_fwd(n, h, w, cin, cout, 3, 1, 'SAME')
-    lib.call('tg_igemm_colsum_' + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(yd), sa, len(segs), lib.ptr(sums), st())
+    lib.call('tg_igemm_colsum_' + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(yd), sa, len(segs), lib.ptr(sums), 0, st())
     pre_hip = yd.cpu().numpy().copy()
     scale = np.abs(x).max() * np.abs(wt).max() * 9 * cin
     assert np.abs(pre_hip - pre).max() <= 3e-5 * scale
@@ -247,7 +247,7 @@ def test_fused_mean_only_batch_norm_forward_backward(prec, segs, h):
     dx_ref, db_ref = np.concatenate(dx_ref), t.sum(axis=(0, 1, 2))
     dyd, dxd, dbd = dev(dy), torch.full((n, h, w, cout), 7.0, device='cuda'), torch.full((cout,), 7.0, device='cuda')
     lib.call('tg_mobn_bwd_f32', lib.ptr(dyd), cout, lib.ptr(yd), cout, lib.ptr(dxd), cout, n * h * w, cout, sa, len(segs), lib.ACT['lrelu'], 0.2,
-             lib.ptr(sums), lib.ptr(dbd), st())
+             lib.ptr(sums), 0, lib.ptr(dbd), st())
     np.testing.assert_allclose(dxd.cpu().numpy(), dx_ref, rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(dbd.cpu().numpy(), db_ref, rtol=1e-5, atol=1e-4)
 
