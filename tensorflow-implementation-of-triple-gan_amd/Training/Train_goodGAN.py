@@ -235,29 +235,33 @@ class Train(Train_base):
             self._graphs = {}
         graphs = self._graphs.setdefault(key, [None] * len(segs))
         pending = []
-        for i, (fn, grads, overlap) in enumerate(segs):
-            if grads is None:                           # the classifier's optimiser step: needs every bucket
-                for wk in pending:
-                    tgdist.wait_(wk)
-                pending = []
-            if use_graph and self._warm:
-                if graphs[i] is None:
-                    import ctypes as C
-                    lib.call('tg_graph_begin_capture', cx.stream)
-                    try:
-                        fn()
-                    finally:
-                        h = C.c_void_p()
-                        lib.call('tg_graph_end_capture', cx.stream, C.byref(h))
-                    graphs[i] = h
-                lib.call('tg_graph_launch', graphs[i], cx.stream)
-            else:
-                fn()
-            if grads is not None and self.world > 1:
-                if overlap:
-                    pending.append(tgdist.allreduce_sum_async_(grads))
+        cx.prep_cache = {}                              # filter layouts stay valid between a network's optimiser steps
+        try:
+            for i, (fn, grads, overlap) in enumerate(segs):
+                if grads is None:                           # the classifier's optimiser step: needs every bucket
+                    for wk in pending:
+                        tgdist.wait_(wk)
+                    pending = []
+                if use_graph and self._warm:
+                    if graphs[i] is None:
+                        import ctypes as C
+                        lib.call('tg_graph_begin_capture', cx.stream)
+                        try:
+                            fn()
+                        finally:
+                            h = C.c_void_p()
+                            lib.call('tg_graph_end_capture', cx.stream, C.byref(h))
+                        graphs[i] = h
+                    lib.call('tg_graph_launch', graphs[i], cx.stream)
                 else:
-                    tgdist.allreduce_sum_(grads)
+                    fn()
+                if grads is not None and self.world > 1:
+                    if overlap:
+                        pending.append(tgdist.allreduce_sum_async_(grads))
+                    else:
+                        tgdist.allreduce_sum_(grads)
+        finally:
+            cx.prep_cache = None
         self._warm = True
         self.iteration += 1
 

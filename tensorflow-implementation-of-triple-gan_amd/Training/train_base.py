@@ -36,6 +36,7 @@ class Train_base(object):
 
     def _train_op(self, optimizer, store, grad_scale=1.0):
         """optimizer.minimize(loss, var_list) (train_base.py:64-68): the gradients are already in store.g."""
+        ctx().prep_invalidate(store)
         optimizer.apply(store, grad_scale)
 
     # ---- _loss_GAN split by solver (each writes value + d/dlogits) --------------------------------

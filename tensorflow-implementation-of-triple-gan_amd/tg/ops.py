@@ -91,16 +91,26 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     t = k * k
     needs_w = cx.trains() and kernel_grad is not None
     needs_x = cx.tape is not None and x.requires_grad
-    scale = None
-    with cx.on_side(forward=True):                 # weights are final since the phase's fork: runs ahead, beside the previous layer's launch
-        # (buffers written on the side stream are also ALLOCATED under it: a first-use zero fill is a launch on the current stream)
-        w_oti = cx.scratch('woti', co_p * t * ci_p)
-        w_hwio = cx.scratch('whwio', t * ci_p * co_p) if needs_x else None
-        if wn is not None:
-            scale = cx.scratch('wns', c_out)
-            _call('tg_wn_scale_f32', _p(kernel), _p(wn[0]), t * c_in, c_out, _p(scale), cx.stream)
-        _call('tg_filter_prep_f32', _p(kernel), _p(scale), None, t, c_in, c_out, ci_p, co_p, _p(w_hwio), _p(w_oti), t * ci_p, ci_p, cx.stream)
-    cx.main_waits_side()
+    # MFMA-side filter layouts (+ weight-norm scale).  Inside Train.train_iteration the result is kept per variable until that
+    # network's optimiser step: the classifier is prepared once for the D-update's forward passes and the C-update, the
+    # discriminator once for the G- and C-updates (Context.prep_cache; None outside train_iteration: no caching).
+    key = ('conv', kernel.data_ptr(), wn[0].data_ptr() if wn is not None else 0, t, c_in, c_out, ci_p, co_p)
+    ent = cx.prep_cache.get(key) if cx.prep_cache is not None else None
+    if ent is not None and (ent[2] is not None or not needs_x):
+        scale, w_oti, w_hwio = ent
+    else:
+        scale = None
+        with cx.on_side(forward=True):                 # weights are final since the phase's fork: runs ahead, beside the previous layer's launch
+            # (buffers written on the side stream are also ALLOCATED under it: a first-use zero fill is a launch on the current stream)
+            w_oti = cx.scratch('woti', co_p * t * ci_p)
+            w_hwio = cx.scratch('whwio', t * ci_p * co_p) if (needs_x or cx.prep_cache is not None) else None
+            if wn is not None:
+                scale = cx.scratch('wns', c_out)
+                _call('tg_wn_scale_f32', _p(kernel), _p(wn[0]), t * c_in, c_out, _p(scale), cx.stream)
+            _call('tg_filter_prep_f32', _p(kernel), _p(scale), None, t, c_in, c_out, ci_p, co_p, _p(w_hwio), _p(w_oti), t * ci_p, ci_p, cx.stream)
+        cx.main_waits_side()
+        if cx.prep_cache is not None:
+            cx.prep_cache[key] = (scale, w_oti, w_hwio)
     if n_store_ld is None:
         n_store, ld_out = c_out, co_p
     else:

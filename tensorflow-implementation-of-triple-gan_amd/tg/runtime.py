@@ -206,6 +206,7 @@ class Context(object):
         self.side_forward = mode == '1'
         # fp64 statistics accumulators (fused mean-only BN / batch norm) of one solver run live in ONE arena per phase, zeroed by one
         # launch at the start of the phase instead of one memset per layer and direction (36 -> 3 launches per iteration)
+        self.prep_cache = None         # {layout key: prepared filter buffers} while Train.train_iteration runs (see ops.conv2d)
         self._zarena = {}              # phase -> dict(sizes=[...], buf=tensor or None, cursor=int, recording=bool)
         self._events = {}
         self._side_depth = 0
@@ -293,6 +294,14 @@ class Context(object):
     def scratch(self, tag, numel):
         self.counter += 1
         return self.ws('%s/%s%d' % (self.phase, tag, self.counter), numel)
+
+    def prep_invalidate(self, store):
+        """drop the prepared filter layouts of `store`'s variables (its optimiser step is about to change them)."""
+        if self.prep_cache:
+            lo = store.p.data_ptr()
+            hi = lo + store.p.numel() * 4
+            for k in [k for k in self.prep_cache if lo <= k[1] < hi]:
+                del self.prep_cache[k]
 
     def zscratch(self, tag, numel):
         """(tensor, zeroed) for a statistics accumulator of `numel` floats (= numel/2 doubles).  The first time a phase runs the
