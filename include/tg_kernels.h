@@ -170,7 +170,7 @@ int tg_mobn_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, i
 int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows, int nseg, const double* sums, const float* b, float* pop_mean,
                       float decay, int act, float alpha, void* stream);
 /* fused backward of mean-only BN + nonlinearity: dx = dy*act'(yact) - mean_seg(dy*act'(yact)), db[k] = sum over all rows
- * (db may be NULL).  sums: scratch of nseg*c doubles (sums_zeroed as colsum_zeroed above).  Two launches (sums with fp64 atomics, apply).  c <= 512, c % 4 == 0;
+ * (db may be NULL).  sums: scratch of 8*nseg*c doubles (8 replicas of the accumulators; sums_zeroed as colsum_zeroed above).  Two launches (sums with fp64 atomics, apply).  c <= 512, c % 4 == 0;
  * segments of any size. */
 int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
                     int act, float alpha, double* sums, int sums_zeroed, float* db, void* stream);
@@ -179,7 +179,7 @@ int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nse
 /* Fused training-mode batch norm over application segments (two launches): per segment s and column k
  *   mean = sum x / n_s, var = sum x^2 / n_s - mean^2 (fp64), y = gamma*(x-mean)/sqrt(var+eps) + beta;
  * mean_inv[s][0][k] = mean, mean_inv[s][1][k] = 1/sqrt(var+eps) (for the backward pass); the moving statistics (both NULL: none)
- * are updated sequentially over the segments with the unbiased variance.  sums: scratch of 2*nseg*c doubles.  c need not be a
+ * are updated sequentially over the segments with the unbiased variance.  sums: scratch of 16*nseg*c doubles (8 replicas).  c need not be a
  * multiple of 4 (columns up to the next multiple of 4 are read and written; they must lie inside ld). */
 int tg_bn_train_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int c, const int32_t* seg_rows, int nseg, const float* gamma,
                     const float* beta, float eps, float decay, float* moving_mean, float* moving_var, double* sums, int sums_zeroed, float* mean_inv,

@@ -11,6 +11,8 @@ namespace {
 
 constexpr int RCH = 256;         // rows per stage-1 chunk
 constexpr int MAXSEG = 8;
+constexpr int REPL = 8;          // replicas of a statistics accumulator: workgroup b adds to replica b % REPL, the consumer sums them
+                                 // (same-address fp64 atomics serialise at ~40 ns; 2 048 workgroups -> 64 deep per replica instead of 512)
 
 struct SegTable { int nseg; int rows[MAXSEG]; };
 
@@ -278,9 +280,16 @@ __global__ void __launch_bounds__(256) mobn_bwd_sums(const float* __restrict__ d
       const float4 t = red[k * c4 + cg];
       acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
     }
-    double* o = sums + (int64_t)seg * c + cg * 4;
+    double* o = sums + ((int64_t)(blockIdx.x % REPL) * st.nseg + seg) * c + cg * 4;
     atomicAdd(o, (double)acc.x); atomicAdd(o + 1, (double)acc.y); atomicAdd(o + 2, (double)acc.z); atomicAdd(o + 3, (double)acc.w);
   }
+}
+
+__device__ __forceinline__ double repl_sum(const double* __restrict__ sums, int nseg, int seg, int c, int k) {
+  double t = 0.;
+#pragma unroll
+  for (int r = 0; r < REPL; ++r) t += sums[((int64_t)r * nseg + seg) * c + k];      // fixed order
+  return t;
 }
 
 __global__ void __launch_bounds__(256) mobn_bwd_apply(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
@@ -289,11 +298,11 @@ __global__ void __launch_bounds__(256) mobn_bwd_apply(const float* __restrict__ 
   __shared__ float shift[512];
   int seg, r0, r1;
   if (!bn_chunk(st, 32, blockIdx.x, &seg, &r0, &r1)) return;
-  for (int k = threadIdx.x; k < c; k += 256) shift[k] = -(float)(sums[(int64_t)seg * c + k] / (double)st.rows[seg]);
+  for (int k = threadIdx.x; k < c; k += 256) shift[k] = -(float)(repl_sum(sums, st.nseg, seg, c, k) / (double)st.rows[seg]);
   if (blockIdx.x == 0 && db) {
     for (int k = threadIdx.x; k < c; k += 256) {
       double t = 0.;
-      for (int s = 0; s < st.nseg; ++s) t += sums[(int64_t)s * c + k];
+      for (int s = 0; s < st.nseg; ++s) t += repl_sum(sums, st.nseg, s, c, k);
       db[k] = (float)t;
     }
   }
@@ -439,11 +448,23 @@ __global__ void __launch_bounds__(256) bn_sums(const float* __restrict__ a, int 
     for (int k = 0; k < 4; ++k) {
       const int col = c0 + cg * 4 + k;
       if (col < c) {
-        atomicAdd(sums + ((int64_t)seg * 2 + 0) * c + col, s0[k]);
-        atomicAdd(sums + ((int64_t)seg * 2 + 1) * c + col, s1[k]);
+        double* o = sums + (((int64_t)(blockIdx.x % REPL) * st.nseg + seg) * 2) * c + col;
+        atomicAdd(o, s0[k]);
+        atomicAdd(o + c, s1[k]);
       }
     }
   }
+}
+
+// S0 / S1 of (segment, column) summed over the replicas (layout [REPL][nseg][2][c]); fixed order
+__device__ __forceinline__ void bn_repl(const double* __restrict__ sums, int nseg, int seg, int c, int col, double* s0, double* s1) {
+  double a = 0., b = 0.;
+#pragma unroll
+  for (int r = 0; r < REPL; ++r) {
+    const double* o = sums + (((int64_t)r * nseg + seg) * 2) * c + col;
+    a += o[0]; b += o[c];
+  }
+  *s0 = a; *s1 = b;
 }
 
 __global__ void __launch_bounds__(256) bn_train_apply(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int c, SegTable st, int chunk,
@@ -460,8 +481,10 @@ __global__ void __launch_bounds__(256) bn_train_apply(const float* __restrict__ 
     if (k < ncol) {
       const int col = c0 + k;
       const double n = (double)st.rows[seg];
-      const double mu = sums[((int64_t)seg * 2) * c + col] / n;
-      double var = sums[((int64_t)seg * 2 + 1) * c + col] / n - mu * mu;
+      double q0, q1;
+      bn_repl(sums, st.nseg, seg, c, col, &q0, &q1);
+      const double mu = q0 / n;
+      double var = q1 / n - mu * mu;
       var = var > 0. ? var : 0.;
       const float inv = 1.f / sqrtf((float)var + eps);
       a = gamma[col] * inv;
@@ -476,8 +499,10 @@ __global__ void __launch_bounds__(256) bn_train_apply(const float* __restrict__ 
       float m_run = mm ? mm[col] : 0.f, v_run = mv ? mv[col] : 0.f;
       for (int s = 0; s < st.nseg; ++s) {
         const double n = (double)st.rows[s];
-        const double mu = sums[((int64_t)s * 2) * c + col] / n;
-        double var = sums[((int64_t)s * 2 + 1) * c + col] / n - mu * mu;
+        double q0, q1;
+        bn_repl(sums, st.nseg, s, c, col, &q0, &q1);
+        const double mu = q0 / n;
+        double var = q1 / n - mu * mu;
         var = var > 0. ? var : 0.;
         mean_inv[((int64_t)s * 2) * c + col] = (float)mu;
         mean_inv[((int64_t)s * 2 + 1) * c + col] = 1.f / sqrtf((float)var + eps);
@@ -519,8 +544,10 @@ __global__ void __launch_bounds__(256) bn_train_bwd_apply(const float* __restric
       const int col = c0 + k;
       const float mu = mean_inv[((int64_t)seg * 2) * c + col], inv = mean_inv[((int64_t)seg * 2 + 1) * c + col], g = gamma[col];
       const float m = (float)st.rows[seg];
-      const float dbt = (float)sums[((int64_t)seg * 2) * c + col];
-      const float dgm = inv * (float)(sums[((int64_t)seg * 2 + 1) * c + col] - (double)mu * sums[((int64_t)seg * 2) * c + col]);   // sum dy * xhat
+      double q0, q1;
+      bn_repl(sums, st.nseg, seg, c, col, &q0, &q1);
+      const float dbt = (float)q0;
+      const float dgm = inv * (float)(q1 - (double)mu * q0);   // sum dy * xhat
       a = g * inv;
       b = -g * inv * inv * dgm / m;
       cc = -a * dbt / m - b * mu;
@@ -533,9 +560,10 @@ __global__ void __launch_bounds__(256) bn_train_bwd_apply(const float* __restric
       double dg = 0., db = 0.;
       for (int s = 0; s < st.nseg; ++s) {
         const double mu = (double)mean_inv[((int64_t)s * 2) * c + col], inv = (double)mean_inv[((int64_t)s * 2 + 1) * c + col];
-        const double sdy = sums[((int64_t)s * 2) * c + col];
+        double sdy, sdyx;
+        bn_repl(sums, st.nseg, s, c, col, &sdy, &sdyx);
         db += sdy;
-        dg += inv * (sums[((int64_t)s * 2 + 1) * c + col] - mu * sdy);
+        dg += inv * (sdyx - mu * sdy);
       }
       dgamma[col] = (float)dg;
       dbeta[col] = (float)db;
@@ -677,13 +705,13 @@ int tg_mobn_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, i
   return TG_OK;
 }
 
-// Row-chunk size of the statistics launches: every workgroup ends with one fp64 atomic per column, and the adds to one address
-// serialise at ~40 ns each — 800 chunks of a 25 600-row tensor cost 33 us where the data pass itself takes 3.  At most 128
-// chunks per segment keeps that tail under ~5 us; 128 workgroups still pull a large tensor at HBM rate (a CU takes in > 60 GB/s).
+// Row-chunk size of the statistics launches: ~2 048 workgroups over all segments for a large tensor (a streaming pass needs
+// many waves in flight), never less than 32 rows.  Every workgroup ends with one fp64 atomic per column into replica
+// (workgroup % REPL) of the accumulator: <= 64 same-address adds per replica and segment, a tail of a few microseconds.
 static int stats_chunk(const SegTable& st) {
-  int mx = 0;
-  for (int s = 0; s < st.nseg; ++s) mx = st.rows[s] > mx ? st.rows[s] : mx;
-  int ch = ((mx + 127) / 128 + 31) / 32 * 32;
+  int64_t tot = 0;
+  for (int s = 0; s < st.nseg; ++s) tot += st.rows[s];
+  int ch = (int)(((tot + 2047) / 2048 + 31) / 32 * 32);
   return ch < 32 ? 32 : ch;
 }
 
@@ -716,7 +744,7 @@ int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, flo
              "mobn_bwd: c=%d vs ld unsupported", c);
   hipStream_t s = tg::as_stream(stream);
   if (!sums_zeroed) {
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * nseg * c, s);
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * REPL * nseg * c, s);
     if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(mobn_bwd sums)");
   }
   tg::ProfScope prof(tg::PC_NORM, 0, 20.0 * rows * c, s);
@@ -760,7 +788,7 @@ int tg_bn_train_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int 
   TG_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_train: moving_mean / moving_var must both be given or both be NULL");
   hipStream_t s = tg::as_stream(stream);
   if (!sums_zeroed) {
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * nseg * c, s);
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * REPL * 2 * nseg * c, s);
     if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn sums)");
   }
   tg::ProfScope prof(tg::PC_NORM, 0, 12.0 * rows * c, s);
@@ -785,7 +813,7 @@ int tg_bn_train_bwd_f32(const float* dy, int ld_dy, const float* x, int ld_x, fl
   TG_REQUIRE(c > 0 && ld_dy % 4 == 0 && ld_x % 4 == 0 && ld_dx % 4 == 0 && cp <= ld_dy && cp <= ld_x && cp <= ld_dx, "bn_train_bwd: c=%d vs ld", c);
   hipStream_t s = tg::as_stream(stream);
   if (!sums_zeroed) {
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * nseg * c, s);
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * REPL * 2 * nseg * c, s);
     if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn bwd sums)");
   }
   tg::ProfScope prof(tg::PC_NORM, 0, 20.0 * rows * c, s);

@@ -156,7 +156,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
             pass
         elif mobn is not None and c_out == co_p and c_out <= 512 and len(seg_rows) <= 8:
             db = mobn[1] if needs_w else cx.scratch('db', c_out)
-            sums64, zd = cx.zscratch('bs64', 2 * len(seg_rows) * c_out)
+            sums64, zd = cx.zscratch('bs64', 16 * len(seg_rows) * c_out)     # 8 replicas x nseg x c doubles
             _call('tg_mobn_bwd_f32', gy.ptr, gy.ld, y.ptr, y.ld, _p(dpre), co_p, y.rows, c_out, seg_array(seg_rows), len(seg_rows),
                   ACT[act], alpha, _p(sums64), zd, _p(db), cx.stream)
         elif mobn is not None:
@@ -266,7 +266,7 @@ def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_g
     needs = cx.tape is not None and (x.requires_grad or trains)
     seg_rows = _segs(x, segments)
     nseg = len(seg_rows)
-    sums, zd = cx.zscratch('bn64', 4 * nseg * c)              # 2*nseg*c doubles
+    sums, zd = cx.zscratch('bn64', 32 * nseg * c)             # 8 replicas x 2 x nseg x c doubles
     mean_inv = cx.scratch('bnmi', 2 * nseg * c)
     y = cx.new_act(x.n, x.h, x.w, c, x.ld, requires_grad=needs)
     _call('tg_bn_train_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, seg_array(seg_rows), nseg, _p(gamma), _p(beta), eps, decay, _p(mm), _p(mv),
@@ -279,7 +279,7 @@ def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_g
         assert gy is not None
         want = trains and gamma_grad is not None
         gx = cx.grad_of(x)
-        bsums, zdb = cx.zscratch('bnb64', 4 * nseg * c)
+        bsums, zdb = cx.zscratch('bnb64', 32 * nseg * c)
         _call('tg_bn_train_bwd_f32', gy.ptr, gy.ld, x.ptr, x.ld, gx.ptr, gx.ld, x.rows, c, seg_array(seg_rows), nseg, _p(gamma), _p(mean_inv),
               1 if relu_input else 0, _p(bsums), zdb, _p(gamma_grad) if want else None, _p(beta_grad) if want else None, cx.stream)
 

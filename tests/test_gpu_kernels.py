@@ -220,7 +220,7 @@ def test_fused_mean_only_batch_norm_forward_backward(prec, segs, h):
     w_oti[:] = wt.reshape(9, cin, cout).transpose(2, 0, 1)
     xd, wd, bd, popd = dev(x), dev(w_oti), dev(b), dev(pop0)
     yd = torch.full((n, h, w, cout), 7.0, device='cuda')
-    sums = torch.zeros(2 * len(segs) * cout, device='cuda')          # nseg*c doubles
+    sums = torch.zeros(16 * len(segs) * cout, device='cuda')         # room for the 8 accumulator replicas of tg_mobn_bwd_f32
     d = geom.conv_fwd(n, h, w, cin, cout, 3, 1, 'SAME')
     lib.call('tg_igemm_colsum_' + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(yd), sa, len(segs), lib.ptr(sums), 0, st())
     pre_hip = yd.cpu().numpy().copy()
@@ -267,3 +267,54 @@ def test_slab_reduce_both_paths(n_split, t, c_pad, n_pad, c, n):
     got = out[0].cpu().numpy()
     assert np.abs(got - ref).max() <= 2e-6 * np.abs(slab).sum(0).max()
     assert torch.equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("segs,hw,c,ld", [([3, 5], 6, 128, 128), ([50, 50, 100], 1, 10, 32), ([7], 4, 300, 320), ([2, 1, 4], 8, 64, 64)])
+def test_fused_segmented_batch_norm(segs, hw, c, ld):
+    """tg_bn_train_f32 / tg_bn_train_bwd_f32 against the oracle's batch_norm_train(+_bwd) applied per application segment
+    (Model/modle_base.py:229-237): ragged segments, a channel count that is not a multiple of 4 (the [N,10] logits), more than
+    one 256-column block; moving statistics updated segment by segment with the Bessel-corrected variance."""
+    lib = _lib()
+    rng = np.random.default_rng(3)
+    n = sum(segs)
+    x = (rng.standard_normal((n, hw, hw, c)) * 2 + 0.7).astype(np.float32)
+    gamma, beta = rng.standard_normal(c).astype(np.float32), rng.standard_normal(c).astype(np.float32)
+    mm0, mv0 = rng.standard_normal(c).astype(np.float32), (rng.random(c) + 0.5).astype(np.float32)
+    dy = rng.standard_normal(x.shape).astype(np.float32)
+    seg_rows = [s * hw * hw for s in segs]
+    sa = (C.c_int32 * len(segs))(*seg_rows)
+    y_ref, dx_ref, dg_ref, db_ref = [], [], np.zeros(c), np.zeros(c)
+    mm, mv, o = mm0.astype(np.float64), mv0.astype(np.float64), 0
+    for s in segs:
+        xs = x[o:o + s].astype(np.float64)
+        ys, cache = T.batch_norm_train(xs, gamma.astype(np.float64), beta.astype(np.float64), 1e-5)
+        mm, mv = T.batch_norm_moving_update(mm, mv, cache[2], cache[3], s * hw * hw, 0.9, True)
+        dxs, dg, db = T.batch_norm_train_bwd(dy[o:o + s].astype(np.float64), gamma.astype(np.float64), cache)
+        y_ref.append(ys); dx_ref.append(dxs); dg_ref += dg; db_ref += db
+        o += s
+    y_ref, dx_ref = np.concatenate(y_ref), np.concatenate(dx_ref)
+
+    def pad(a):
+        out = np.zeros(a.shape[:-1] + (ld,), np.float32)
+        out[..., :c] = a
+        return out
+    xd, dyd = dev(pad(x)), dev(pad(dy))
+    gd, bd, mmd, mvd = dev(gamma), dev(beta), dev(mm0), dev(mv0)
+    yd, dxd = torch.full((n, hw, hw, ld), 7.0, device='cuda'), torch.full((n, hw, hw, ld), 7.0, device='cuda')
+    sums = torch.zeros(32 * len(segs) * c, device='cuda')
+    mean_inv = torch.zeros(2 * len(segs) * c, device='cuda')
+    dgd, dbd = torch.full((c,), 7.0, device='cuda'), torch.full((c,), 7.0, device='cuda')
+    rows = n * hw * hw
+    lib.call('tg_bn_train_f32', lib.ptr(xd), ld, lib.ptr(yd), ld, rows, c, sa, len(segs), lib.ptr(gd), lib.ptr(bd), 1e-5, 0.9, lib.ptr(mmd), lib.ptr(mvd),
+             lib.ptr(sums), 0, lib.ptr(mean_inv), st())
+    lib.call('tg_bn_train_bwd_f32', lib.ptr(dyd), ld, lib.ptr(xd), ld, lib.ptr(dxd), ld, rows, c, sa, len(segs), lib.ptr(gd), lib.ptr(mean_inv), 0,
+             lib.ptr(sums), 0, lib.ptr(dgd), lib.ptr(dbd), st())
+    y = yd.cpu().numpy()
+    np.testing.assert_allclose(y[..., :c], y_ref, rtol=2e-5, atol=2e-5)
+    cp = (c + 3) // 4 * 4
+    assert (y[..., c:cp] == 0).all()                                  # columns up to the next multiple of 4 are written as zeros
+    np.testing.assert_allclose(dxd.cpu().numpy()[..., :c], dx_ref, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dgd.cpu().numpy(), dg_ref, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(dbd.cpu().numpy(), db_ref, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(mmd.cpu().numpy(), mm, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mvd.cpu().numpy(), mv, rtol=1e-4, atol=1e-6)
