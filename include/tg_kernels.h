@@ -219,6 +219,11 @@ int tg_cond_concat_f32(const float* x, int ld_x, int c, const float* mask, int l
 /* out[r][:c] = dy[r][:c]*mask*mscale*act'(yact[r][:c]), zero up to ld_out (mask, yact may be NULL). */
 int tg_actgrad_f32(const float* dy, int ld_dy, const float* yact, int ld_y, const float* mask, int ld_mask, float mscale, float* out, int ld_out,
                    int rows, int c, int act, float alpha, void* stream);
+/* the same for a layer with a bias (no mask): out = dy*act'(yact) (yact NULL: out = dy), padding zeroed up to ld_out, AND
+ * bias_grad[k] = sum over rows of out[:,k] in the same pass (tf.nn.bias_add gradient).  sums: scratch of 8*c doubles
+ * (sums_zeroed as in tg_igemm_colsum_f32).  ld_out % 4 == 0. */
+int tg_actgrad_bias_f32(const float* dy, int ld_dy, const float* yact, int ld_y, float* out, int ld_out, int rows, int c, int act, float alpha,
+                        double* sums, int sums_zeroed, float* bias_grad, void* stream);
 /* tf.nn.max_pool 2x2 s2 (Good_GAN_cifar10.py:123,142) fused with the dropout that follows (:124,143). */
 int tg_maxpool2_fwd_f32(const float* y, int ld_y, float* out, int ld_out, const float* mask, int ld_mask, float mscale, int n, int h, int w, int c,
                         void* stream);

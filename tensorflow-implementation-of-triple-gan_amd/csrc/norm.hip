@@ -322,6 +322,57 @@ __global__ void __launch_bounds__(256) mobn_bwd_apply(const float* __restrict__ 
   }
 }
 
+// dpre = dy * act'(yact) (pad columns zeroed up to ld_out) AND its column sums (the bias gradient of a plain conv / transposed conv /
+// dense layer) in one pass: per-workgroup partial sums -> one fp64 atomic per column into replica (workgroup % REPL); a second tiny
+// launch adds the replicas.  Replaces actgrad + two-stage colstats (three launches, two passes over dpre).
+__global__ void __launch_bounds__(256) actgrad_bias(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
+                                                    float* __restrict__ out, int ld_out, int rows, int c, int act, float alpha, int chunk,
+                                                    double* __restrict__ sums) {
+  const int r0 = blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
+  const int g4 = ld_out >> 2;                         // column groups of the output row (covers the padding)
+  const int lanes = 256 / g4 > 0 ? 256 / g4 : 1;
+  const int cg = threadIdx.x % g4, rl = threadIdx.x / g4;
+  __shared__ float4 red[256];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (rl < lanes) {
+    for (int r = r0 + rl; r < r1; r += lanes) {
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int col = cg * 4 + k;
+        float t = 0.f;
+        if (col < c) {
+          t = dy[(int64_t)r * ld_dy + col];
+          if (y) t *= tgd::act_grad(y[(int64_t)r * ld_y + col], act, alpha);
+        }
+        v[k] = t;
+        acc[k] += t;
+      }
+      *reinterpret_cast<float4*>(out + (int64_t)r * ld_out + cg * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  red[threadIdx.x] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < lanes; ++k) {
+      const float4 t = red[k * g4 + cg];
+      acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (cg * 4 + k < c) atomicAdd(sums + (int64_t)(blockIdx.x % REPL) * c + cg * 4 + k, (double)acc[k]);
+  }
+}
+
+__global__ void repl_finalize(const double* __restrict__ sums, int c, float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= c) return;
+  double t = 0.;
+#pragma unroll
+  for (int r = 0; r < REPL; ++r) t += sums[(int64_t)r * c + k];
+  out[k] = (float)t;
+}
+
 __global__ void mobn_finalize(const float* __restrict__ sums, SegTable st, int c, const float* __restrict__ b, float* __restrict__ pop, float decay,
                               int train, float* __restrict__ shift) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
@@ -753,6 +804,25 @@ int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, flo
   TG_CHECK_LAUNCH("mobn_bwd_sums");
   hipLaunchKernelGGL(mobn_bwd_apply, dim3(seg_chunks(st, 32)), dim3(256), 0, s, dy, ld_dy, yact, ld_y, dx, ld_dx, rows, c, st, act, alpha, sums, db);
   TG_CHECK_LAUNCH("mobn_bwd_apply");
+  return TG_OK;
+}
+
+int tg_actgrad_bias_f32(const float* dy, int ld_dy, const float* yact, int ld_y, float* out, int ld_out, int rows, int c, int act, float alpha,
+                        double* sums, int sums_zeroed, float* bias_grad, void* stream) {
+  TG_REQUIRE(dy && out && sums && bias_grad && rows > 0 && c > 0, "actgrad_bias: bad args");
+  TG_REQUIRE(c <= ld_dy && c <= ld_out && (!yact || c <= ld_y) && ld_out % 4 == 0 && ld_out <= 1024, "actgrad_bias: c=%d ld_out=%d unsupported", c, ld_out);
+  hipStream_t s = tg::as_stream(stream);
+  if (!sums_zeroed) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * REPL * c, s);
+    if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(actgrad_bias sums)");
+  }
+  tg::ProfScope prof(tg::PC_ELEMWISE, 0, 4.0 * rows * (ld_out + 2 * c), s);
+  int chunk = ((rows + 2047) / 2048 + 31) / 32 * 32;
+  if (chunk < 32) chunk = 32;
+  hipLaunchKernelGGL(actgrad_bias, dim3((rows + chunk - 1) / chunk), dim3(256), 0, s, dy, ld_dy, yact, ld_y, out, ld_out, rows, c, act, alpha, chunk, sums);
+  TG_CHECK_LAUNCH("actgrad_bias");
+  hipLaunchKernelGGL(repl_finalize, dim3((c + 255) / 256), dim3(256), 0, s, sums, c, bias_grad);
+  TG_CHECK_LAUNCH("repl_finalize");
   return TG_OK;
 }
 

@@ -166,6 +166,10 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
             _call('tg_mobn_bwd_finalize_f32', _p(sums), seg_array(seg_rows), len(seg_rows), y.rows, c_out, _p(sh), _p(db), cx.stream)
             _call('tg_seg_actgrad_shift_f32', gy.ptr, gy.ld, y.ptr, y.ld, _p(dpre), co_p, y.rows, c_out, seg_array(seg_rows),
                   len(seg_rows), _p(sh), ACT[act], alpha, cx.stream)
+        elif needs_w and bias_grad is not None and co_p <= 1024:
+            zs, zd = cx.zscratch('ab64', 16 * c_out)
+            _call('tg_actgrad_bias_f32', gy.ptr, gy.ld, y.ptr if act else None, y.ld, _p(dpre), co_p, y.rows, c_out, ACT[act], alpha,
+                  _p(zs), zd, _p(bias_grad), cx.stream)
         else:
             _call('tg_actgrad_f32', gy.ptr, gy.ld, y.ptr if act else None, y.ld, None, 0, 1.0, _p(dpre), co_p, y.rows, c_out,
                   ACT[act], alpha, cx.stream)
@@ -219,11 +223,16 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
         gy = y.grad
         assert gy is not None
         dpre = cx.scratch('dpre', y.rows * co_p)
-        _call('tg_actgrad_f32', gy.ptr, gy.ld, y.ptr if act else None, y.ld, None, 0, 1.0, _p(dpre), co_p, y.rows, c_out,
-              ACT[act], 0.2, cx.stream)
-        if needs_w:
-            if bias_grad is not None:
+        if needs_w and bias_grad is not None and co_p <= 1024:
+            zs, zd = cx.zscratch('ab64', 16 * c_out)
+            _call('tg_actgrad_bias_f32', gy.ptr, gy.ld, y.ptr if act else None, y.ld, _p(dpre), co_p, y.rows, c_out, ACT[act], 0.2,
+                  _p(zs), zd, _p(bias_grad), cx.stream)
+        else:
+            _call('tg_actgrad_f32', gy.ptr, gy.ld, y.ptr if act else None, y.ld, None, 0, 1.0, _p(dpre), co_p, y.rows, c_out,
+                  ACT[act], 0.2, cx.stream)
+            if needs_w and bias_grad is not None:
                 colstats(0, dpre, co_p, None, 0, y.rows, c_out, [y.rows], s1=bias_grad)
+        if needs_w:
             if wn is None:
                 filter_grad(geom.deconv_wgrad(x.n, x.h, x.w, co_p, ci_p), dpre, x.t, 25, c_out, c_in, kernel_grad)
             else:

@@ -318,3 +318,28 @@ def test_fused_segmented_batch_norm(segs, hw, c, ld):
     np.testing.assert_allclose(dbd.cpu().numpy(), db_ref, rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(mmd.cpu().numpy(), mm, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(mvd.cpu().numpy(), mv, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows,c,ld_out,act", [(1000, 32, 32, 'lrelu'), (77, 3, 32, 'tanh'), (5000, 138, 160, None), (64, 1, 32, None)])
+def test_actgrad_with_bias_gradient(rows, c, ld_out, act):
+    """tg_actgrad_bias_f32: dpre = dy*act'(y) with zeroed padding and bias_grad = column sums of dpre, in one pass."""
+    lib = _lib()
+    rng = np.random.default_rng(2)
+    dy = rng.standard_normal((rows, c)).astype(np.float32)
+    y = np.tanh(rng.standard_normal((rows, c))).astype(np.float32)
+    if act == 'lrelu':
+        ref = T.lrelu_bwd_from_out(y.astype(np.float64), dy.astype(np.float64), 0.2)
+    elif act == 'tanh':
+        ref = dy.astype(np.float64) * (1 - y.astype(np.float64) ** 2)
+    else:
+        ref = dy.astype(np.float64)
+    dyd, ydv = dev(dy), dev(y)
+    out = torch.full((rows, ld_out), 7.0, device='cuda')
+    sums = torch.zeros(16 * c, device='cuda')
+    bg = torch.full((c,), 7.0, device='cuda')
+    lib.call('tg_actgrad_bias_f32', lib.ptr(dyd), c, lib.ptr(ydv) if act else None, c, lib.ptr(out), ld_out, rows, c, lib.ACT[act], 0.2,
+             lib.ptr(sums), 0, lib.ptr(bg), st())
+    o = out.cpu().numpy()
+    np.testing.assert_allclose(o[:, :c], ref, rtol=1e-6, atol=1e-6)
+    assert (o[:, c:] == 0).all()
+    np.testing.assert_allclose(bg.cpu().numpy(), ref.sum(0), rtol=1e-5, atol=1e-4)
