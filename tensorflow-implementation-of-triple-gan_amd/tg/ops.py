@@ -118,6 +118,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     fused_act = act if mobn is None else None
     d = geom.conv_fwd(x.n, x.h, x.w, ci_p, co_p, k, stride, padding, ld_out=ld_out, n_store=n_store, act=fused_act, alpha=alpha)
     y = cx.new_act(x.n, d.h_out, d.w_out, c_out, ld_out, requires_grad=needs_w or needs_x)
+    y.strided_grad_ok = True
     seg_rows = _segs(y, segments)
     fused = (mobn is not None and train and c_out == co_p and c_out <= 512 and stride == 1 and _colsum_tile_exists(c_out, seg_rows))
     if fused:
@@ -214,6 +215,7 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
     cx.main_waits_side()
     ld_out = c_out if narrow_out else co_p
     y = cx.new_act(x.n, 2 * x.h, 2 * x.w, c_out, ld_out, requires_grad=needs_w or needs_x)
+    y.strided_grad_ok = True
     dds = lib.desc_array(geom.deconv_fwd(x.n, x.h, x.w, ci_p, co_p, ld_out=ld_out, n_store=c_out, act=act))
     _call('tg_igemm_multi_f32', C.cast(dds, C.c_void_p), len(dds), x.ptr, _p(w_pad), _p(bias), y.ptr, cx.stream)
     if not (needs_w or needs_x):
@@ -319,8 +321,14 @@ def cond_concat(x, y_onehot_t, ncls):
     _call('tg_cond_concat_f32', x.ptr, x.ld, x.c, None, 0, 1.0, _p(y_onehot_t), ncls, out.ptr, ld, x.n, x.h * x.w, cx.stream)
     if cx.tape is not None and x.requires_grad:
         def bwd():   # gradient of the first x.c channels; the label channels are constants
-            gx = cx.grad_of(x)
-            _call('tg_actgrad_f32', out.grad.ptr, out.grad.ld, None, 0, None, 0, 1.0, gx.ptr, gx.ld, x.rows, x.c, 0, 0.0, cx.stream)
+            g = out.grad
+            if x.grad is None and x.strided_grad_ok:
+                # no copy: x's gradient IS the leading channels of the concatenated gradient (every consumer of an activation
+                # gradient reads it through (pointer, channel stride))
+                x.grad = Act(g.t, x.n, x.h, x.w, x.c, g.ld)
+            else:
+                gx = cx.grad_of(x)
+                _call('tg_actgrad_f32', g.ptr, g.ld, None, 0, None, 0, 1.0, gx.ptr, gx.ld, x.rows, x.c, 0, 0.0, cx.stream)
         cx.record(bwd)
     return out
 

@@ -26,12 +26,13 @@ def pad32(c):
 class Act(object):
     """Handle of an NHWC activation buffer: logical shape [n,h,w,c], channel stride ld >= c
     (channels c..ld are zero when the buffer feeds an MFMA kernel)."""
-    __slots__ = ('t', 'n', 'h', 'w', 'c', 'ld', 'grad', 'requires_grad')
+    __slots__ = ('t', 'n', 'h', 'w', 'c', 'ld', 'grad', 'requires_grad', 'strided_grad_ok')
 
     def __init__(self, t, n, h, w, c, ld, requires_grad=False):
         self.t, self.n, self.h, self.w, self.c, self.ld = t, n, h, w, c, ld
         self.grad = None
         self.requires_grad = requires_grad
+        self.strided_grad_ok = False      # set by producers whose backward reads .grad through (pointer, channel stride) only
 
     @property
     def rows(self):
