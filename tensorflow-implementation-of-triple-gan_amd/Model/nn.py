@@ -21,11 +21,21 @@ def int_shape(x):
     return [x.n, x.h, x.w, x.c] if (x.h, x.w) != (1, 1) else [x.n, x.c]
 
 
+def mean_only_batch_norm_impl(x, pop_mean, b, is_conv_out=True, deterministic=False, decay=0.9, name='meanOnlyBatchNormalization',
+                              b_grad=None, segments=None):
+    """Model/nn.py:147-187 as a stand-alone function: x - mean + b with the running mean updated (training) or x - pop_mean + b
+    (deterministic).  pop_mean / b: device tensors (e.g. ctx().var(...)); is_conv_out only selects the reduction axes in the
+    reference ([0,1,2] vs [0]) — here every row of the activation is one sample of the statistic either way.  The models use
+    the version fused into the convolution (conv2d_WN / dense_WN)."""
+    with ctx().variable_scope(name):
+        return ops.mean_only_batch_norm(x, pop_mean, b, b_grad=b_grad, train=not deterministic, decay=decay, segments=segments)
+
+
 def _wn_layer(x, num_out, k, pad, stride, nonlinearity, use_weight_normalization, use_batch_normalization,
               use_mean_only_batch_normalization, deterministic, segments):
     if use_batch_normalization or not use_weight_normalization or not use_mean_only_batch_normalization:
         raise NotImplementedError("only the weight-norm + mean-only-BN path is executed by the reference's models "
-                                  "(Model/Good_GAN_cifar10.py:106-172)")
+                                  "(Model/Good_GAN_cifar10.py:106-172); batch_norm_impl (nn.py:192-218) is never enabled")
     cx = ctx()
     act = getattr(nonlinearity, 'tg_act', None) if nonlinearity is not None else None
     if nonlinearity is not None and act is None:

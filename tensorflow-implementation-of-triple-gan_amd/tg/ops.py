@@ -251,6 +251,45 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
     return y
 
 
+def mean_only_batch_norm(x, pop_mean, b, b_grad=None, train=True, decay=0.9, segments=None):
+    """x - mean + b (training, pop_mean updated) or x - pop_mean + b (Model/nn.py:147-187) as a stand-alone op on an activation
+    (the layers of the models use the version fused into the convolution, conv2d(mobn=...))."""
+    cx = ctx()
+    c = x.c
+    seg_rows = _segs(x, segments)
+    nseg = len(seg_rows)
+    needs = cx.tape is not None and (x.requires_grad or (cx.trains() and b_grad is not None))
+    y = cx.new_act(x.n, x.h, x.w, c, x.ld, requires_grad=needs)
+    y.strided_grad_ok = True
+    sums = None
+    if train:
+        sums, _ = colstats(0, x.t, x.ld, None, 0, x.rows, c, seg_rows)
+    shift = cx.scratch('shift', nseg * c)
+    _call('tg_mobn_finalize_f32', _p(sums), seg_array(seg_rows), nseg, x.rows, c, _p(b), _p(pop_mean), decay, 1 if train else 0, _p(shift), cx.stream)
+    _call('tg_seg_scale_shift_act_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, c, seg_array(seg_rows), nseg, None, _p(shift), 0, 0.0, cx.stream)
+    if not needs:
+        return y
+    want_b = cx.trains() and b_grad is not None
+
+    def bwd():
+        gy = y.grad
+        assert gy is not None
+        gx = cx.grad_of(x)
+        if train:
+            s1, _ = colstats(0, gy.t, gy.ld, None, 0, x.rows, c, seg_rows)
+            sh = cx.scratch('bshift', nseg * c)
+            db = b_grad if want_b else cx.scratch('db', c)
+            _call('tg_mobn_bwd_finalize_f32', _p(s1), seg_array(seg_rows), nseg, x.rows, c, _p(sh), _p(db), cx.stream)
+            _call('tg_seg_actgrad_shift_f32', gy.ptr, gy.ld, gy.ptr, gy.ld, gx.ptr, gx.ld, x.rows, c, seg_array(seg_rows), nseg, _p(sh), 0, 0.0, cx.stream)
+        else:
+            _call('tg_actgrad_f32', gy.ptr, gy.ld, None, 0, None, 0, 1.0, gx.ptr, gx.ld, x.rows, c, 0, 0.0, cx.stream)
+            if want_b:
+                colstats(0, gy.t, gy.ld, None, 0, x.rows, c, [x.rows], s1=b_grad)
+
+    cx.record(bwd)
+    return y
+
+
 # ------------------------------------------------------------------ batch norm (tf.contrib.layers.batch_norm, training mode)
 
 def batch_norm_eval(x, gamma, beta, mm, mv, eps):

@@ -135,3 +135,40 @@ def test_zca_matches_oracle(trainer):
     with cx.phase_scope('T4', record=False):
         out = m.zca().apply(cx.from_numpy(x))
     assert G.rel_err(out.numpy(), N.zca_apply(x, mean, mat)) < ACT_TOL
+
+
+def test_standalone_mean_only_batch_norm_impl():
+    """Model/nn.py:147-187 as a free function: training (two application segments, pop_mean chain, gradients) and deterministic mode."""
+    import torch
+    from Model import nn as tnn
+    tr = G.fresh_trainer(G.make_config(dict(B_G=8, L_C=4, U_C=4, L_D=2, U_D=6)))
+    cx = tr.cx
+    rng = np.random.default_rng(4)
+    segs, h, c = [3, 2], 6, 64
+    x = rng.standard_normal((5, h, h, c)).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    pop0 = rng.standard_normal(c).astype(np.float32)
+    dy = rng.standard_normal(x.shape).astype(np.float32)
+    pop = pop0.astype(np.float64)
+    y_ref, dx_ref, o = [], [], 0
+    for s in segs:
+        yy, pop = T.mobn_train(x[o:o + s].astype(np.float64), pop, b.astype(np.float64))
+        dxs, _ = T.mobn_train_bwd(dy[o:o + s].astype(np.float64))
+        y_ref.append(yy); dx_ref.append(dxs)
+        o += s
+    bd, pd = torch.from_numpy(b).cuda(), torch.from_numpy(pop0).cuda()
+    bg = torch.zeros(c, device='cuda')
+    with cx.phase_scope('Tm', train_nets=('classifier',)):
+        with cx.variable_scope('classifier'):
+            xa = cx.from_numpy(x)
+            xa.requires_grad = True
+            ya = tnn.mean_only_batch_norm_impl(xa, pd, bd, deterministic=False, b_grad=bg, segments=segs)
+            ya.grad = cx.from_numpy(dy)
+            cx.backward()
+    assert G.rel_err(ya.numpy(), np.concatenate(y_ref)) < 1e-5
+    assert G.rel_err(xa.grad.numpy(), np.concatenate(dx_ref)) < 1e-5
+    assert G.rel_err(pd.cpu().numpy(), pop) < 1e-5
+    assert G.rel_err(bg.cpu().numpy(), dy.astype(np.float64).sum((0, 1, 2))) < 1e-5
+    with cx.phase_scope('Tm2', record=False):
+        ye = tnn.mean_only_batch_norm_impl(cx.from_numpy(x), pd, bd, deterministic=True)
+    assert G.rel_err(ye.numpy(), T.mobn_eval(x.astype(np.float64), pop, b.astype(np.float64))) < 1e-5
