@@ -4,7 +4,9 @@
 //   tg_wgrad_f32 : slab[s][t][c][n] = sum_{p in split s} in[pix(p,t),c] * dout[p,n]
 //
 // One kernel family serves conv fwd (SAME/VALID, stride 1/2), conv input-gradient, 5x5 s2 transposed conv
-// (one launch per output parity), dense / NiN / ZCA (1 tap) — the geometry lives in tg_igemm_desc.
+// (the four output parities as sub-problems of ONE launch), dense / NiN / ZCA (1 tap) — the geometry lives in tg_igemm_desc.
+// Template variants: COLSUM (tg_igemm_colsum_*: the mean-only-BN column sums of the output accumulated in the epilogue, lane =
+// channel operand order) and BF16 (tg_*_bf16: operands rounded to bf16 on the way LDS -> registers, v_mfma_f32_32x32x16_bf16).
 //
 // CDNA4 mapping
 //  * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = the fp32 roofline, 157 TFLOP/s chip).
@@ -15,7 +17,10 @@
 //    bank-conflict free for the 16-lane / 8-lane groups of gfx950.
 //  * register-staged double buffering: global loads of tile i+1 are issued before the 64 MFMAs of tile i and
 //    written to the other LDS buffer after them; one barrier per K-tile; 2 workgroups per CU (76 KB LDS each).
-//  * NHWC gathers are 16 B per lane, 128 B contiguous per 8 lanes; out-of-image taps load nothing.
+//  * NHWC gathers are 16 B per lane, 128 B contiguous per 8 lanes, through buffer descriptors: an out-of-image tap is an
+//    out-of-range offset that the hardware turns into zeros (no branch, no select); the K-tile position rides in the scalar
+//    offset operand.  The fp32 MFMA executes on the vector ALUs, so the K loop carries next to no VALU address arithmetic.
+//  * workgroup order is XCD-aware in both kernels (tiles that share operand rows meet in one XCD's L2).
 #include <cstdio>
 #include <cstdlib>
 #include "tg_common.h"

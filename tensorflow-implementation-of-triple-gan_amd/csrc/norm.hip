@@ -1,6 +1,10 @@
-// HBM-bound statistics / normalisation kernels: per-(application segment, channel) column sums with a
-// deterministic two-stage reduction (wavefront-free of atomics), mean-only batch-norm and batch-norm
-// finalisers, and the fused shift/scale + activation passes (forward and backward).
+// HBM-bound statistics / normalisation kernels.
+//  * fused paths (what the models run): mean-only batch norm (apply after tg_igemm_colsum_*, backward statistics + apply) and
+//    training-mode batch norm (statistics + apply, forward and backward), per application segment; statistics are per-workgroup
+//    partial sums -> one fp64 atomic per column into one of REPL replicas of the accumulator (the fp64 sum of fp32 terms is
+//    order-insensitive to ~1e-16, so replays are bit-identical after the cast to float);
+//  * generic building blocks (shapes the fused paths do not take, evaluation mode): per-(segment, channel) column sums with a
+//    deterministic two-stage reduction, finalisers, shift/scale + activation passes.
 //
 // Access pattern: rows are NHWC pixels, channels contiguous; every lane moves 16 B (float4), a block's 32
 // column-groups cover 512 contiguous bytes per row, 8 rows in flight per pass.
