@@ -77,6 +77,10 @@ typedef struct tg_igemm_desc {
   int64_t w_sn, w_st;            /* weight element (n,t,c) at n*w_sn + tapw[t]*w_st + c (c contiguous) */
   int32_t act;                   /* TG_ACT_* applied after +bias */
   float alpha;                   /* leaky slope */
+  int32_t n_group;               /* 0: off.  > 0 (tg_igemm_f32 / _bf16 only): GEMM column n is channel n % n_group of output pixel
+                                  * (v_y*os_y + oo_y + g / os_x, v_x*os_x + oo_x + g % os_x), g = n / n_group; stored if channel < n_store;
+                                  * bias indexed by channel.  A stride-2 transposed conv then is ONE balanced 3x3 problem with
+                                  * 4 * n_group columns (zero weights for the taps a parity does not have) instead of four unequal ones. */
 } tg_igemm_desc;
 
 /* out[p,n] = act( sum_t sum_c in[pix(p,t),c] * w[n,t,c] + bias[n] ).
@@ -136,6 +140,11 @@ int tg_filter_prep_f32(const float* src, const float* scale, const float* scale_
 int tg_wn_scale_tab_f32(const float* v, const float* g, int t, int a, int b, float* scale_a, void* stream);
 int tg_wn_bwd_tab_f32(const float* dw, const float* v, const float* g, int t, int a, int b, float* dv, float* dg, void* stream);
 
+/* Merged filter of a stride-2 transposed conv for a tg_igemm_desc with n_group: dst[g*n_group + co][t9][c] (zero padded to
+ * [n_pad][9][c_pad]) = w[tapmap[g*9 + t9]][co][c] * scale_a[co] (scale_a may be NULL), 0 where tapmap is negative.
+ * w: [25][c_out][c_in] (tf conv2d_transpose filter [kh,kw,Cout,Cin]); tapmap: HOST array of 36 entries. */
+int tg_deconv_merge_prep_f32(const float* w, const float* scale_a, int c_out, int c_in, int n_group, int n_pad, int c_pad,
+                             const int32_t* tapmap, float* dst, void* stream);
 /* dst[t][c][n] = sum_s slab[s][t][c][n] (c < c_dim, n < n_dim): finishes tg_wgrad_f32, drops channel padding. */
 int tg_slab_reduce_f32(const float* slab, int n_split, int t, int c_pad, int n_pad, int c_dim, int n_dim, float* dst, void* stream);
 

@@ -69,6 +69,7 @@ constexpr uint32_t OOB_OFF = 0x80000000u;   // byte offset beyond any (< 2 GiB) 
 struct SubDesc {
   int32_t h_v, w_v, s_y, s_x, h_out, w_out, ld_out, os_y, os_x, oo_y, oo_x, n_store, n_taps, act;
   float alpha;
+  int32_t n_group;
   int32_t taps[TG_MAX_TAPS];     // (tapw << 16) | ((dy & 0xff) << 8) | (dx & 0xff)
 };
 
@@ -344,7 +345,8 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     }
     return;
   }
-  const bool vec_ok = (d.n_store & 3) == 0 && (d.ld_out & 3) == 0;
+  const int ng = d.n_group;                                    // > 0: column -> (output-pixel parity, channel), see tg_igemm_desc
+  const bool vec_ok = (d.n_store & 3) == 0 && (d.ld_out & 3) == 0 && (ng & 3) == 0;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const uint32_t ro = t_ob[wm0 + mi * 32 + col];
@@ -353,22 +355,36 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + wn0 + ni * 32 + 8 * q + 4 * half;
+        int ch[4];
+        uint32_t goff[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ng > 0) {
+            const int g = (n + e) / ng;
+            ch[e] = n + e - g * ng;
+            goff[e] = (uint32_t)(((g / d.os_x) * d.w_out + (g % d.os_x)) * d.ld_out) * 4u;
+            if (g >= d.os_x * d.os_y) ch[e] = d.n_store;          // padding columns behind the last group: never stored
+          } else {
+            ch[e] = n + e;
+            goff[e] = 0;
+          }
+        }
         float va[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float t = acc[mi][ni][4 * q + e];
-          if (p.bias != nullptr && n + e < d.n_store) t += p.bias[n + e];
+          if (p.bias != nullptr && ch[e] < d.n_store) t += p.bias[ch[e]];
           va[e] = apply_act(t, d.act, d.alpha);
         }
         if (vec_ok) {
-          const uint32_t off = ((ro & OOB_OFF) || n >= d.n_store) ? OOB_OFF : ro + (uint32_t)n * 4u;
+          const uint32_t off = ((ro & OOB_OFF) || ch[0] >= d.n_store) ? OOB_OFF : ro + goff[0] + (uint32_t)ch[0] * 4u;
           const u32x4 pk = {__builtin_bit_cast(uint32_t, va[0]), __builtin_bit_cast(uint32_t, va[1]), __builtin_bit_cast(uint32_t, va[2]),
                             __builtin_bit_cast(uint32_t, va[3])};
           __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_o, off, 0, 0);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const uint32_t off = ((ro & OOB_OFF) || n + e >= d.n_store) ? OOB_OFF : ro + (uint32_t)(n + e) * 4u;
+            const uint32_t off = ((ro & OOB_OFF) || ch[e] >= d.n_store) ? OOB_OFF : ro + goff[e] + (uint32_t)ch[e] * 4u;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, va[e]), rsrc_o, off, 0, 0);
           }
         }
@@ -603,7 +619,10 @@ int check_desc(const tg_igemm_desc* d) {
   TG_REQUIRE(d->n_img > 0 && d->h_v > 0 && d->w_v > 0 && d->h_in > 0 && d->w_in > 0, "igemm: empty geometry");
   TG_REQUIRE(d->n_store >= 0 && d->n_store <= d->c_out && d->n_store <= d->ld_out, "igemm: n_store=%d vs c_out=%d ld_out=%d",
              d->n_store, d->c_out, d->ld_out);
-  TG_REQUIRE((d->h_v - 1) * d->os_y + d->oo_y < d->h_out && (d->w_v - 1) * d->os_x + d->oo_x < d->w_out && d->oo_y >= 0 && d->oo_x >= 0,
+  TG_REQUIRE(d->n_group >= 0 && (d->n_group == 0 || (d->n_store <= d->n_group && d->n_group * d->os_y * d->os_x <= d->c_out)),
+             "igemm: n_group=%d vs n_store=%d c_out=%d os=%dx%d", d->n_group, d->n_store, d->c_out, d->os_y, d->os_x);
+  const int gy_ = d->n_group ? d->os_y - 1 : 0, gx_ = d->n_group ? d->os_x - 1 : 0;
+  TG_REQUIRE((d->h_v - 1) * d->os_y + d->oo_y + gy_ < d->h_out && (d->w_v - 1) * d->os_x + d->oo_x + gx_ < d->w_out && d->oo_y >= 0 && d->oo_x >= 0,
              "igemm: virtual grid %dx%d (stride %d,%d offset %d,%d) exceeds output %dx%d", d->h_v, d->w_v, d->os_y, d->os_x,
              d->oo_y, d->oo_x, d->h_out, d->w_out);
   TG_REQUIRE((int64_t)d->n_img * d->h_in * d->w_in * d->ld_in < (1LL << 31) && (int64_t)d->n_img * d->h_out * d->w_out * d->ld_out < (1LL << 31),
@@ -652,6 +671,7 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
     k.h_v = e.h_v; k.w_v = e.w_v; k.s_y = e.s_y; k.s_x = e.s_x; k.h_out = e.h_out; k.w_out = e.w_out; k.ld_out = e.ld_out;
     k.os_y = e.os_y; k.os_x = e.os_x; k.oo_y = e.oo_y; k.oo_x = e.oo_x; k.n_store = e.n_store; k.n_taps = e.n_taps; k.act = e.act;
     k.alpha = e.alpha;
+    k.n_group = e.n_group;
     for (int t = 0; t < e.n_taps; ++t)
       k.taps[t] = ((int32_t)e.tapw[t] << 16) | (((int32_t)e.dy[t] & 0xff) << 8) | ((int32_t)e.dx[t] & 0xff);
   }
@@ -752,6 +772,7 @@ extern "C" int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float
 static int igemm_colsum_impl(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
                              double* colsum, int colsum_zeroed, void* stream, bool bf16) {
   TG_REQUIRE(d && colsum && seg_rows && nseg >= 1 && nseg <= 8, "igemm_colsum: bad args");
+  TG_REQUIRE(d->n_group == 0, "igemm_colsum: grouped columns are not supported");
   TG_REQUIRE(d->act == TG_ACT_NONE, "igemm_colsum: the statistics are of the raw convolution output (no activation)");
   int tot = 0;
   for (int i = 0; i < nseg; ++i) { TG_REQUIRE(seg_rows[i] >= 32, "igemm_colsum: segment %d has %d rows (need at least one 32-row tile)", i, seg_rows[i]); tot += seg_rows[i]; }
@@ -797,6 +818,7 @@ static int wgrad_impl(const tg_igemm_desc* d, const float* in, const float* dout
   TG_REQUIRE(in && dout && slab, "wgrad: null buffer");
   TG_REQUIRE(n_split >= 1, "wgrad: n_split=%d", n_split);
   TG_REQUIRE(d->c_out <= d->ld_out, "wgrad: c_out=%d exceeds ld_out=%d", d->c_out, d->ld_out);
+  TG_REQUIRE(d->n_group == 0, "wgrad: grouped columns are not supported");
   WgradParams p{in, dout, slab, *d, 0, n_split, 0, 0, 0, 0, 0};
   p.M = d->n_img * d->h_v * d->w_v;
   const int64_t ib = (int64_t)d->n_img * d->h_in * d->w_in * d->ld_in * 4, ob = (int64_t)d->n_img * d->h_out * d->w_out * d->ld_out * 4;

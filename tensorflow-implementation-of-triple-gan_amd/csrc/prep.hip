@@ -103,6 +103,29 @@ __global__ void __launch_bounds__(256) filter_prep(const float* __restrict__ src
   }
 }
 
+struct TapMap { int32_t m[36]; };
+
+// merged transposed-conv filter (see tg_deconv_merge_prep_f32): one thread per destination element, c fastest
+__global__ void __launch_bounds__(256) deconv_merge_prep(const float* __restrict__ w, const float* __restrict__ scale_a, int c_out, int c_in,
+                                                         int n_group, int n_pad, int c_pad, TapMap tm, float* __restrict__ dst) {
+  const int64_t total = (int64_t)n_pad * 9 * c_pad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c_pad);
+    const int64_t nt = i / c_pad;
+    const int t9 = (int)(nt % 9), n = (int)(nt / 9);
+    const int g = n / n_group, co = n - g * n_group;
+    float v = 0.f;
+    if (g < 4 && co < c_out && c < c_in) {
+      const int tap = tm.m[g * 9 + t9];
+      if (tap >= 0) {
+        v = w[((int64_t)tap * c_out + co) * c_in + c];
+        if (scale_a) v *= scale_a[co];
+      }
+    }
+    dst[i] = v;
+  }
+}
+
 // dst[t][c][n] = sum_s slab[s][t][c][n], c < C, n < N  (fixed summation order -> bitwise reproducible)
 __global__ void __launch_bounds__(256) slab_reduce(const float* __restrict__ slab, int n_split, int t_dim, int c_pad, int n_pad, int c_dim, int n_dim,
                                                    float* __restrict__ dst) {
@@ -220,6 +243,19 @@ int tg_filter_prep_f32(const float* src, const float* scale, const float* scale_
   hipLaunchKernelGGL(filter_prep, dim3((a_pad + 31) / 32, (b_pad + 31) / 32, t), dim3(256), 0, s, src, scale, scale_a, a, b, a_pad, b_pad, dst_same,
                      dst_tr, tr_sb, tr_st);
   TG_CHECK_LAUNCH("filter_prep");
+  return TG_OK;
+}
+
+int tg_deconv_merge_prep_f32(const float* w, const float* scale_a, int c_out, int c_in, int n_group, int n_pad, int c_pad,
+                             const int32_t* tapmap, float* dst, void* stream) {
+  TG_REQUIRE(w && dst && tapmap && c_out > 0 && c_in > 0 && n_group >= c_out && n_pad >= 4 * n_group && c_pad >= c_in, "deconv_merge_prep: bad args");
+  TapMap tm;
+  for (int i = 0; i < 36; ++i) { tm.m[i] = tapmap[i]; TG_REQUIRE(tapmap[i] < 25, "deconv_merge_prep: tap %d out of range", tapmap[i]); }
+  hipStream_t s = tg::as_stream(stream);
+  const int64_t total = (int64_t)n_pad * 9 * c_pad;
+  tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * (total + 25.0 * c_out * c_in), s);
+  hipLaunchKernelGGL(deconv_merge_prep, dim3(ew_grid(total)), dim3(256), 0, s, w, scale_a, c_out, c_in, n_group, n_pad, c_pad, tm, dst);
+  TG_CHECK_LAUNCH("deconv_merge_prep");
   return TG_OK;
 }
 

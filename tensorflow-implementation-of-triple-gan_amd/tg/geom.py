@@ -94,6 +94,38 @@ def deconv_fwd(n, h, w, ld_in, c_out_pad, k=5, stride=2, ld_out=None, n_store=No
     return descs
 
 
+def deconv_fwd_merged(n, h, w, ld_in, c_out, ld_out, n_store=None, act=None):
+    """The same transposed conv (5x5, stride 2) as ONE 3x3 problem over the input grid whose GEMM columns are (output parity,
+    channel): the parities have 9/6/6/4 of the 25 taps, so four separate sub-problems leave the matrix pipes unevenly loaded;
+    here every workgroup does 9 taps and the missing ones are zero weights (36/25 of the arithmetic, but balanced — and for a
+    3-channel image layer the four parities share one 32-column tile instead of padding 3 to 32 four times).
+    Returns (descriptor, n_group, tapmap[36]) — tapmap[g*9 + t9] = index of the 5x5 tap, -1 where the parity has none."""
+    k, stride = 5, 2
+    _, pt, _ = same_pad(h * stride, k, stride)
+    _, pl, _ = same_pad(w * stride, k, stride)
+    n_group = c_out if c_out % 4 == 0 else c_out        # channels per parity group (vector stores need a multiple of 4)
+    n_pad = pad32(4 * n_group)
+    tapmap = [-1] * 36
+    for py in range(stride):
+        for px in range(stride):
+            g = py * stride + px
+            for ky in range(k):
+                if (py + pt - ky) % stride:
+                    continue
+                for kx in range(k):
+                    if (px + pl - kx) % stride:
+                        continue
+                    dy, dx = (py + pt - ky) // stride, (px + pl - kx) // stride
+                    assert -1 <= dy <= 1 and -1 <= dx <= 1
+                    tapmap[g * 9 + (dy + 1) * 3 + (dx + 1)] = ky * k + kx
+    taps = [(dy, dx, (dy + 1) * 3 + (dx + 1)) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    n_store = c_out if n_store is None else n_store
+    d = _desc(n, h, w, ld_in, h, w, (1, 1), h * stride, w * stride, ld_out, (stride, stride), (0, 0), n_pad, n_store, taps,
+              9 * ld_in, ld_in, act)
+    d.n_group = n_group
+    return d, n_group, tapmap
+
+
 def deconv_dgrad(n, h, w, c_in_pad, ld_dy, k=5, stride=2, ld_out=None, n_store=None):
     """d(in) of deconv_fwd = strided conv of dy [n,2h,2w,ld_dy]; W as [k*k][c_in_pad][ld_dy]
     (per-tap transpose of the filter)."""

@@ -24,6 +24,7 @@ class IgemmDesc(C.Structure):
         ("tapw", C.c_int16 * TG_MAX_TAPS),
         ("w_sn", C.c_int64), ("w_st", C.c_int64),
         ("act", C.c_int32), ("alpha", C.c_float),
+        ("n_group", C.c_int32),
     ]
 
 
@@ -33,7 +34,7 @@ _SCALARS = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint32_
 _RET = {"int": C.c_int, "int64_t": C.c_int64, "const char*": C.c_char_p}
 _NOCHECK = {"tg_version", "tg_last_error_string", "tg_device_count", "tg_prof_num_classes", "tg_prof_class_name",
             "tg_colstats_workspace_floats"}
-HOST_INT_ARRAYS = {"seg_rows"}          # pointer arguments that are HOST arrays
+HOST_INT_ARRAYS = {"seg_rows", "tapmap"}          # pointer arguments that are HOST arrays
 
 
 def _ctype_of(decl):

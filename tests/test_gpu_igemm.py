@@ -126,6 +126,17 @@ def test_deconv5x5s2_fwd_dgrad_wgrad(n, h, w, cin, cout, prec):
         lib.call("tg_igemm_" + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
     close(yd.cpu().numpy(), y_ref, np.abs(x).max() * np.abs(wt).max() * 9 * cin)
 
+    # the same forward as ONE 3x3 problem with (output parity, channel) columns (tg_igemm_desc.n_group) and the merged filter
+    import ctypes as C
+    dm, ng, tapmap = geom.deconv_fwd_merged(n, h, w, ci_p, cout, cout, n_store=cout, act='tanh')
+    assert dm.n_group == ng == cout and sorted(t for t in tapmap if t >= 0) == list(range(25))
+    wraw = dev(wt.reshape(25, cout, cin))
+    wm = torch.full((dm.c_out * 9 * ci_p,), 7.0, device='cuda')
+    lib.call("tg_deconv_merge_prep_f32", lib.ptr(wraw), None, cout, cin, ng, dm.c_out, ci_p, (C.c_int32 * 36)(*tapmap), lib.ptr(wm), lib.cur_stream())
+    ym = torch.full((n, 2 * h, 2 * w, cout), 7.0, device='cuda')
+    lib.call("tg_igemm_" + prec, dm, lib.ptr(xd), lib.ptr(wm), lib.ptr(bd), lib.ptr(ym), lib.cur_stream())
+    close(ym.cpu().numpy(), y_ref, np.abs(x).max() * np.abs(wt).max() * 9 * cin)
+
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
     dyd = dev(padc(dy, co_p))
     dx_ref = T.conv2d_transpose_bwd_input(q(wt), q(dy))
