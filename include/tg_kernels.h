@@ -247,6 +247,9 @@ int tg_gavgpool_bwd_f32(const float* dfeat, int ld_d, const float* yact, int ld_
                         float alpha, void* stream);
 int tg_copy2d_f32(const float* src, int64_t ld_s, float* dst, int64_t ld_d, int64_t rows, int64_t c, void* stream);
 int tg_fill_f32(float* dst, float value, int64_t n, void* stream);
+/* out[m][n] = bias[n] + sum_s part[m][s][n] (bias may be NULL): finishes a dense product whose reduction dimension was split
+ * into s_dim sub-problems of one tg_igemm_multi_f32 launch (skinny GEMMs such as the ZCA product: few rows, long K). */
+int tg_splitk_reduce_f32(const float* part, const float* bias, float* out, int ld_out, int64_t m, int s_dim, int n, void* stream);
 /* input-pipeline tail on the device (Input_Pipeline/cifar10Dataset.py:52-62): dst = float(src)/255 * scale + shift
  * (scale 2, shift -1 for SVHN / CIFAR-10; scale 1, shift 0 for MNIST, mnistDataset.py:65), and tf.one_hot(label, k). */
 int tg_u8_affine_f32(const uint8_t* src, float* dst, int64_t n, float scale, float shift, void* stream);

@@ -255,6 +255,15 @@ class cifar10_ZCA():
         cx = ctx()
         assert image.ld == image.c and image.h * image.w * image.c == self.dim
         out = cx.new_act(image.n, image.h, image.w, image.c, image.c)
-        d = geom.dense_fwd(image.n, self.dim, self.dim)
-        lib.call('tg_igemm_f32', d, image.ptr, lib.ptr(self.wt), lib.ptr(self.bias), out.ptr, cx.stream)
+        splits = 4 if self.dim % 128 == 0 and image.n <= 1024 and os.environ.get('TG_ZCA_SPLITK', '1') != '0' else 1
+        if splits > 1:
+            # few rows, long reduction (3072): four K-ranges as sub-problems of one launch, then one add-up pass
+            import ctypes as C
+            part = cx.scratch('zcap', image.n * splits * self.dim)
+            dds = lib.desc_array(geom.dense_fwd_splitk(image.n, self.dim, self.dim, splits))
+            lib.call('tg_igemm_multi_f32', C.cast(dds, C.c_void_p), len(dds), image.ptr, lib.ptr(self.wt), None, lib.ptr(part), cx.stream)
+            lib.call('tg_splitk_reduce_f32', lib.ptr(part), lib.ptr(self.bias), out.ptr, self.dim, image.n, splits, self.dim, cx.stream)
+        else:
+            d = geom.dense_fwd(image.n, self.dim, self.dim)
+            lib.call('tg_igemm_f32', d, image.ptr, lib.ptr(self.wt), lib.ptr(self.bias), out.ptr, cx.stream)
         return out

@@ -157,3 +157,14 @@ def dense_fwd(m, ld_in, c_out, ld_out=None, n_store=None, act=None, w_sn=None):
     n_store = c_out if n_store is None else n_store
     return _desc(m, 1, 1, ld_in, 1, 1, (1, 1), 1, 1, ld_out, (1, 1), (0, 0), c_out, n_store,
                  [(0, 0, 0)], ld_in if w_sn is None else w_sn, 0, act)
+
+
+def dense_fwd_splitk(m, k_dim, n_out, splits):
+    """y = x @ Wt.T with the reduction dimension cut into `splits` ranges: sub-problem s reads x[:, s*k/splits:(s+1)*k/splits]
+    (the input viewed as `splits` pixels of k/splits channels) against the matching slice of Wt[n][k] and writes partial
+    products to part[m][s][n]; tg_splitk_reduce_f32 adds them up.  For skinny products (few rows, long K: the ZCA matmul of
+    130 / 250 images has only ~150 tiles of 96 K-steps) this multiplies the number of workgroups by `splits`."""
+    assert k_dim % (32 * splits) == 0
+    kc = k_dim // splits
+    return [_desc(m, 1, splits, kc, 1, 1, (1, 1), 1, splits, n_out, (1, 1), (0, s), n_out, n_out, [(0, s, s)], k_dim, kc)
+            for s in range(splits)]
