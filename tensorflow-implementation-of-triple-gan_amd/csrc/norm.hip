@@ -338,20 +338,33 @@ __global__ void __launch_bounds__(256) actgrad_bias(const float* __restrict__ dy
   const int cg = threadIdx.x % g4, rl = threadIdx.x / g4;
   __shared__ float4 red[256];
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool vec = (c & 3) == 0 && (ld_dy & 3) == 0 && (!y || (ld_y & 3) == 0);
   if (rl < lanes) {
     for (int r = r0 + rl; r < r1; r += lanes) {
-      float v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int col = cg * 4 + k;
-        float t = 0.f;
-        if (col < c) {
-          t = dy[(int64_t)r * ld_dy + col];
-          if (y) t *= tgd::act_grad(y[(int64_t)r * ld_y + col], act, alpha);
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (vec) {
+        if (cg * 4 < c) {
+          const float4 g = *reinterpret_cast<const float4*>(dy + (int64_t)r * ld_dy + cg * 4);
+          v[0] = g.x; v[1] = g.y; v[2] = g.z; v[3] = g.w;
+          if (y) {
+            const float4 yy = *reinterpret_cast<const float4*>(y + (int64_t)r * ld_y + cg * 4);
+            v[0] *= tgd::act_grad(yy.x, act, alpha); v[1] *= tgd::act_grad(yy.y, act, alpha);
+            v[2] *= tgd::act_grad(yy.z, act, alpha); v[3] *= tgd::act_grad(yy.w, act, alpha);
+          }
         }
-        v[k] = t;
-        acc[k] += t;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int col = cg * 4 + k;
+          if (col < c) {
+            float t = dy[(int64_t)r * ld_dy + col];
+            if (y) t *= tgd::act_grad(y[(int64_t)r * ld_y + col], act, alpha);
+            v[k] = t;
+          }
+        }
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += v[k];
       *reinterpret_cast<float4*>(out + (int64_t)r * ld_out + cg * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
