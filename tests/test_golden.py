@@ -1,0 +1,24 @@
+"""Golden vectors of SURVEY §8c (tests/golden/cifar10_small_k10.npz, written by tests/golden/make_golden.py from the float64
+restatement): the oracle must keep reproducing them (guards the checker against accidental edits)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+
+
+def golden():
+    return np.load(os.path.join(HERE, 'golden', 'cifar10_small_k10.npz'))
+
+
+def test_oracle_reproduces_the_golden_prefix():
+    import make_golden as M
+    g = golden()
+    out = M.run(k_steps=2)                                   # two of the ten iterations keep the CPU suite short
+    np.testing.assert_allclose(out['losses'], g['losses'][:2], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(out['sample_init'], g['sample_init'], rtol=0, atol=1e-6)        # stored as float32
+    np.testing.assert_allclose(out['logits_init'], g['logits_init'], rtol=1e-9, atol=1e-12)
+    assert out['acc_init'] == float(g['acc_init'])
+    assert g['losses'].shape == (10, 3) and g['sample_final'].shape == (8, 32, 32, 3) and g['logits_final'].shape == (M.N_TEST, 10)
