@@ -266,7 +266,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline_one_iteration()
         print(json.dumps(out), flush=True)
     tgdist.barrier()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

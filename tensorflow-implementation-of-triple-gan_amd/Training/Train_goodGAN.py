@@ -85,7 +85,7 @@ class Train(Train_base):
         self.g_optimizer = self._Adam_optimizer(self.hyper[0:1], c.BETA1)
         self.c_optimizer = self._Adam_optimizer(self.hyper[1:2], 0.5)
         self.set_hyper(c.LEARNING_RATE, getattr(c, 'CLA_LEARNINIG_RATE', c.LEARNING_RATE), 0.0, 0.0)
-        if self.world > 1:                       # identical initial weights on every replica
+        if tgdist.active():                      # identical initial weights on every replica
             for s in st.values():
                 tgdist.broadcast_(s.p)
                 tgdist.broadcast_(s.s)
@@ -187,7 +187,7 @@ class Train(Train_base):
         w = 1.0 / self.world
         gC = st['classifier'].g
         first = getattr(self.model, 'C_BUCKET_FIRST', None)
-        split = self.world > 1 and first is not None and not getattr(self.config, 'NO_GRAD_BUCKETS', False)
+        split = tgdist.active() and first is not None and not getattr(self.config, 'NO_GRAD_BUCKETS', False)
         if split:
             off = st['classifier'].offset(first)
             c_bwd = [(lambda: self._c_forward_backward(True), gC[off:], True), (self._c_backward_rest, gC[:off], False)]
@@ -255,7 +255,7 @@ class Train(Train_base):
                     lib.call('tg_graph_launch', graphs[i], cx.stream)
                 else:
                     fn()
-                if grads is not None and self.world > 1:
+                if grads is not None and tgdist.active():
                     if overlap:
                         pending.append(tgdist.allreduce_sum_async_(grads))
                     else:
@@ -290,7 +290,7 @@ class Train(Train_base):
     def sync_running_state(self):
         """Replicas keep their own running statistics (pop_mean, batch-norm moving mean / variance) and EMA shadows while
         training; they are averaged over the replicas before evaluation and before a checkpoint is written."""
-        if self.world > 1:
+        if tgdist.active():
             for st in self.cx.stores.values():
                 tgdist.allreduce_mean_(st.s)
                 if st.ema is not None:

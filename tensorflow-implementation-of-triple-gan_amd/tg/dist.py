@@ -8,6 +8,12 @@ import torch
 import torch.distributed as dist
 
 
+# TG_DIST_SINGLE=1: create the process group even for ONE replica and run every collective on it — the RCCL code path
+# (communicator bound to the device, asynchronous bucket all-reduce beside a graph launch, broadcast, barrier) exercised on a
+# one-GPU box; results are unchanged (a one-rank sum is the identity).
+SINGLE = os.environ.get('TG_DIST_SINGLE') == '1'
+
+
 def env_world():
     return int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
 
@@ -15,7 +21,7 @@ def env_world():
 def init(backend=None):
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  Returns (world, rank, local_rank)."""
     world, rank, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or SINGLE) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -37,13 +43,18 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def active():
+    """collectives are issued: more than one replica (or the one-replica RCCL rehearsal)."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or SINGLE)
+
+
 def rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
 
 def allreduce_sum_(flat):
     """in-place sum over replicas of a flat gradient buffer (one collective per network per iteration)."""
-    if world_size() > 1:
+    if active():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
@@ -51,7 +62,7 @@ def allreduce_sum_(flat):
 def allreduce_sum_async_(flat):
     """Start the in-place sum on RCCL's own stream — it waits for what the current stream has enqueued so far and runs beside
     whatever is enqueued next (the remaining backward pass).  Returns a handle for wait_(); None on one replica."""
-    if world_size() > 1:
+    if active():
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
     return None
 
@@ -63,25 +74,25 @@ def wait_(work):
 
 
 def allreduce_mean_(flat):
-    if world_size() > 1:
+    if active():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(world_size())
     return flat
 
 
 def broadcast_(flat, src=0):
-    if world_size() > 1:
+    if active():
         dist.broadcast(flat, src=src)
     return flat
 
 
 def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if world_size() > 1:
+    if active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def barrier():
-    if world_size() > 1:
+    if active():
         dist.barrier()

@@ -1,0 +1,69 @@
+"""RCCL code path on the one-GPU dev box: TG_DIST_SINGLE=1 creates a ONE-replica nccl process group and routes every collective of
+the trainer through it (communicator bound to the device, weight broadcast, bucketed gradient exchange with the asynchronous
+all-reduce beside a hipGraph launch, barrier, max-over-ranks).  A one-rank sum is the identity, so the run must be bit-identical
+to the plain single-process run.  (Several ranks cannot share one GPU under RCCL; tests/test_gpu_dp.py covers two ranks with
+gloo as the transport.)"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "tensorflow-implementation-of-triple-gan_amd"))
+import torch
+import gpu_common as G
+from tg import dist as tgdist
+from oracle import step_cifar10 as S
+sizes = dict(B_G=8, L_C=4, U_C=4, L_D=2, U_D=6)
+tr = G.fresh_trainer(G.make_config(sizes, USE_HIP_GRAPH=True, SEED=5))
+tr.set_hyper(lambda_1=0.3, lambda_2=0.5)
+full = dict(S.SIZES, **sizes)
+for it in range(4):
+    tr.feed(S.synth_batch(it, full))
+    tr.sample_latent()
+    tr.train_iteration()
+tr.sync_running_state()
+tgdist.barrier()
+t = tgdist.max_over_ranks(1.25, tr.cx.device)
+torch.cuda.synchronize()
+out = dict(active=tgdist.active(), backend=(torch.distributed.get_backend() if torch.distributed.is_initialized() else None), t=t,
+           losses=tr.losses(), p={{k: st.p.cpu().numpy() for k, st in tr.cx.stores.items()}})
+torch.save(out, {out!r})
+if torch.distributed.is_initialized():
+    torch.distributed.destroy_process_group()
+'''
+
+
+def _run(tmp_path, single):
+    import torch
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / ('single.pt' if single else 'plain.pt'))
+    script = tmp_path / ('w%d.py' % single)
+    script.write_text(WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    env.pop('TG_DIST_SINGLE', None)
+    if single:
+        env['TG_DIST_SINGLE'] = '1'
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return torch.load(out, weights_only=False)
+
+
+def test_one_replica_rccl_run_is_bit_identical(tmp_path):
+    plain = _run(tmp_path, False)
+    single = _run(tmp_path, True)
+    assert plain['active'] is False and single['active'] is True and single['backend'] == 'nccl'
+    assert single['t'] == 1.25
+    assert single['losses'] == plain['losses']
+    for k in plain['p']:
+        np.testing.assert_array_equal(single['p'][k], plain['p'][k], err_msg=k)
