@@ -16,7 +16,7 @@ import numpy as np
 
 from Model import model_base
 from tg import ops
-from tg.runtime import Act, ParamStore, ctx, pad32
+from tg.runtime import Act, ParamStore, ctx
 
 
 def _trunc_normal(rng, shape):

@@ -13,7 +13,7 @@ Initialisers are applied when the Model creates its variables (see Good_GAN_cifa
 so `kernel_initializer` is accepted and ignored here.
 """
 from tg import ops
-from tg.runtime import ctx, Act
+from tg.runtime import ctx
 
 
 def _act_of(fn):

@@ -26,7 +26,7 @@ from Training.train_base import Train_base
 from tg import dist as tgdist
 from tg import lib, ops
 from tg.batching import concat_acts
-from tg.runtime import Act, Context, InjectedRNG, PhiloxRNG, ctx, set_context
+from tg.runtime import Act, Context, PhiloxRNG, ctx, set_context
 
 
 class Train(Train_base):

@@ -6,7 +6,7 @@ logits' gradient buffers.  `_Adam_optimizer` (:91-97) returns the TF-form Adam c
 tg_adam_f32 over a network's flat buffers; `_train_op` applies it.
 """
 from tg import lib
-from tg.runtime import Act, ctx
+from tg.runtime import ctx
 
 
 class AdamOptimizer(object):
