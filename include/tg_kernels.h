@@ -102,6 +102,17 @@ int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const float* in, 
 int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
                         double* colsum, int colsum_zeroed, void* stream);
 
+/* Input gradient of a convolution whose INPUT was produced by a mean-only-BN layer with nonlinearity `act`: the same launch as
+ * tg_igemm_colsum_f32 (d = the input-gradient geometry, in = dpre of this conv, w = padded HWIO filter), but every output element is
+ * multiplied by act'(yact) (yact = that producing layer's activated output, same shape and channel stride as `out`) before it is
+ * stored and summed:  out = dx * act'(yact),  colsum[seg][k] = sum over the segment's rows of out[:,k].
+ * Together with tg_mobn_center_f32 this replaces tg_mobn_bwd_f32 for that producing layer (its gradient never makes a separate
+ * statistics pass). */
+int tg_igemm_actsum_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* yact, int act, float alpha, float* out,
+                        const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* stream);
+int tg_igemm_actsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* yact, int act, float alpha, float* out,
+                         const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* stream);
+
 /* filter gradient, split over `n_split` pixel ranges:
  * slab[s][t][c][n] = sum_{p in split s} in[pix(p,t),c] * dout[p,n]   (c < ld_in, n < c_out).
  * `dout` is read through (h_out,w_out,ld_out,os,oo) exactly as tg_igemm_f32 writes `out`.
@@ -183,6 +194,10 @@ int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows
  * segments of any size. */
 int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
                     int act, float alpha, double* sums, int sums_zeroed, float* db, void* stream);
+/* second half of the mean-only-BN backward when t = dy*act'(y) and its per-segment column sums already exist (tg_igemm_actsum_f32):
+ * dx = t - sums[seg]/rows_seg (dx may alias t), db[k] = sum_s sums[s][k] (db may be NULL).  sums: [nseg][c] doubles.  c <= 512, c % 4 == 0. */
+int tg_mobn_center_f32(const float* t, int ld_t, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg, const double* sums,
+                       float* db, void* stream);
 /* shift[s][k] = -sums[s][k]/rows_s; db[k] = sum_s sums[s][k]. */
 int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, int rows, int c, float* shift, float* db, void* stream);
 /* Fused training-mode batch norm over application segments (two launches): per segment s and column k

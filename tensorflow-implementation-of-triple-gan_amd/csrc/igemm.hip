@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "tg_common.h"
+#include "tg_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -84,6 +85,9 @@ struct IgemmParams {
   int n_sub, M, m_tiles, n_tiles;
   uint32_t in_bytes, w_bytes, out_bytes;
   double* colsum;                 // COLSUM variant: [nseg][c_out] fp64 accumulators (zeroed by the launcher)
+  const float* ymul;              // COLSUM variant, optional: out = acc * act'(ymul[same position]) (tg_igemm_actsum_*)
+  int ymul_act;
+  float ymul_alpha;
   int nseg, seg_rows[8];
 };
 
@@ -309,38 +313,74 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   const int half = lane >> 5, col = lane & 31;
   const uint32_t* t_ob = reinterpret_cast<const uint32_t*>(t_out);
   if (COLSUM) {
-    // Mean-only-BN variant: the pixel operand was the MFMA row operand, so a lane holds ONE output channel and its 16
-    // registers hold rows — the tile's column sum is 16 adds + one cross-half shuffle per lane, accumulated with fp64
-    // atomics into [segment][channel] (masked rows hold exact zeros; tiles never straddle a segment: launcher check).
-    // A tile may straddle ONE segment boundary (every segment has at least BM rows: launcher check): rows below `bnd` (tile-local)
-    // belong to segment `seg`, the others to seg + 1.
+    // Mean-only-BN variants.  The pixel operand was the MFMA row operand, so a lane holds ONE output channel and its 16 registers
+    // hold rows: storing from that layout means 64 dword stores per lane (and, for tg_igemm_actsum_*, 64 dword loads of the
+    // activation).  The tile goes through LDS instead (the operand tiles are dead after the K loop) and leaves it row-wise:
+    // every thread moves 16-B pieces of pixel rows — coalesced stores, coalesced activation loads — and the column sums are taken
+    // from LDS by (column, row-range) threads.  A tile may straddle ONE application boundary (every segment has at least BM rows:
+    // launcher check): rows below `bnd` (tile-local) belong to segment `seg`, the others to seg + 1.
+    constexpr int TLD = BN + 4;                           // LDS row stride of the transposed tile (floats)
+    static_assert(BM * TLD <= 2 * BM * LDT + 2 * BN * LDT, "the output tile must fit into the operand tiles' LDS");
+    float* tile = smem;
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ymul ? p.ymul : p.out), 0, p.out_bytes, 0x00020000);
     int seg = 0, acc_rows = p.seg_rows[0];
     while (seg < p.nseg - 1 && m0 >= acc_rows) acc_rows += p.seg_rows[++seg];
     const int bnd = acc_rows - m0;                        // >= 1; >= BM when the tile lies inside one segment
     const bool two = bnd < BM && seg + 1 < p.nseg;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int n = n0 + wn0 + ni * 32 + col;
-      const bool nok = n < d.n_store;
-      const uint32_t ncol = nok ? (uint32_t)n * 4u : OOB_OFF;
-      float csum = 0.f, csum2 = 0.f;
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[mi][ni][r];
-          const int rl = wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (rl < bnd) csum += v; else csum2 += v;
-          const uint32_t ro = t_ob[rl];
-          const uint32_t off = (ro | ncol) & OOB_OFF ? OOB_OFF : ro + ncol;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rsrc_o, off, 0, 0);
-        }
+        for (int r = 0; r < 16; ++r)
+          tile[(wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * TLD + wn0 + ni * 32 + col] = acc[mi][ni][r];
+    __syncthreads();
+    constexpr int G4 = BN / 4;                            // 16-B pieces per tile row
+    const bool ym = p.ymul != nullptr;
+    for (int i = tid; i < BM * G4; i += 256) {
+      const int rl = i / G4, cg = i - rl * G4;
+      const uint32_t ro = t_ob[rl];
+      const int n = n0 + cg * 4;
+      const uint32_t off = ((ro & OOB_OFF) || n >= d.n_store) ? OOB_OFF : ro + (uint32_t)n * 4u;
+      const float4 tv = *reinterpret_cast<const float4*>(tile + rl * TLD + cg * 4);
+      float va[4] = {tv.x, tv.y, tv.z, tv.w};
+      if (ym) {      // input gradient times the activation derivative of the layer that produced this conv's input
+        const u32x4 yb = __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, off, 0, 0);          // masked positions read 0
+        const uint32_t y0 = yb.x, y1 = yb.y, y2 = yb.z, y3 = yb.w;
+        va[0] *= tgd::act_grad(__builtin_bit_cast(float, y0), p.ymul_act, p.ymul_alpha);
+        va[1] *= tgd::act_grad(__builtin_bit_cast(float, y1), p.ymul_act, p.ymul_alpha);
+        va[2] *= tgd::act_grad(__builtin_bit_cast(float, y2), p.ymul_act, p.ymul_alpha);
+        va[3] *= tgd::act_grad(__builtin_bit_cast(float, y3), p.ymul_act, p.ymul_alpha);
+        *reinterpret_cast<float4*>(tile + rl * TLD + cg * 4) = make_float4(va[0], va[1], va[2], va[3]);
       }
-      csum += __shfl_xor(csum, 32, 64);
-      if (half == 0 && nok) atomicAdd(p.colsum + (int64_t)seg * p.c_out + n, (double)csum);
-      if (two) {                                          // block-uniform
-        csum2 += __shfl_xor(csum2, 32, 64);
-        if (half == 0 && nok) atomicAdd(p.colsum + (int64_t)(seg + 1) * p.c_out + n, (double)csum2);
+      const u32x4 pk = {__builtin_bit_cast(uint32_t, va[0]), __builtin_bit_cast(uint32_t, va[1]), __builtin_bit_cast(uint32_t, va[2]),
+                        __builtin_bit_cast(uint32_t, va[3])};
+      __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_o, off, 0, 0);
+    }
+    if (ym) __syncthreads();
+    // column sums: thread (column c, part q) adds rows q, q + PARTS, ... of its column (masked rows hold exact zeros)
+    constexpr int PARTS = 256 / BN;
+    float* red = tile + BM * TLD;                         // [2][PARTS][BN] partial sums, behind the tile
+    static_assert(BM * TLD + 2 * PARTS * BN <= 2 * BM * LDT + 2 * BN * LDT, "partial sums must fit as well");
+    {
+      const int c = tid % BN, q = tid / BN;
+      float s1 = 0.f, s2 = 0.f;
+      for (int rl = q; rl < BM; rl += PARTS) {
+        const float v = tile[rl * TLD + c];
+        if (rl < bnd) s1 += v; else s2 += v;
+      }
+      red[q * BN + c] = s1;
+      red[(PARTS + q) * BN + c] = s2;
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int n = n0 + tid;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < PARTS; ++q) { s1 += red[q * BN + tid]; s2 += red[(PARTS + q) * BN + tid]; }
+      if (n < d.n_store) {
+        atomicAdd(p.colsum + (int64_t)seg * p.c_out + n, (double)s1);
+        if (two) atomicAdd(p.colsum + (int64_t)(seg + 1) * p.c_out + n, (double)s2);
       }
     }
     return;
@@ -647,12 +687,14 @@ static void launch_igemm(IgemmParams& p, hipStream_t s, bool bf16) {
 }
 
 static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out, void* stream,
-                      double* colsum, const int32_t* seg_rows, int nseg, bool bf16 = false) {
+                      double* colsum, const int32_t* seg_rows, int nseg, bool bf16 = false, const float* ymul = nullptr, int ymul_act = 0,
+                      float ymul_alpha = 0.f) {
   TG_REQUIRE(descs && n_desc >= 1 && n_desc <= MAX_SUB, "igemm: n_desc=%d out of range", n_desc);
   TG_REQUIRE(in && w && out, "igemm: null buffer");
   IgemmParams p;
   p.in = in; p.w = w; p.bias = bias; p.out = out; p.n_sub = n_desc;
   p.colsum = colsum; p.nseg = nseg;
+  p.ymul = ymul; p.ymul_act = ymul_act; p.ymul_alpha = ymul_alpha;
   for (int i = 0; i < 8; ++i) p.seg_rows[i] = (seg_rows && i < nseg) ? seg_rows[i] : 0;
   const tg_igemm_desc* d = &descs[0];
   // sub-problems longest first: workgroups are dispatched in index order, so the 9-tap parity of a 5x5 s2 transposed
@@ -770,7 +812,8 @@ extern "C" int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float
 }
 
 static int igemm_colsum_impl(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
-                             double* colsum, int colsum_zeroed, void* stream, bool bf16) {
+                             double* colsum, int colsum_zeroed, void* stream, bool bf16, const float* ymul = nullptr, int ymul_act = 0,
+                             float ymul_alpha = 0.f) {
   TG_REQUIRE(d && colsum && seg_rows && nseg >= 1 && nseg <= 8, "igemm_colsum: bad args");
   TG_REQUIRE(d->n_group == 0, "igemm_colsum: grouped columns are not supported");
   TG_REQUIRE(d->act == TG_ACT_NONE, "igemm_colsum: the statistics are of the raw convolution output (no activation)");
@@ -781,7 +824,7 @@ static int igemm_colsum_impl(const tg_igemm_desc* d, const float* in, const floa
     hipError_t e = hipMemsetAsync(colsum, 0, sizeof(double) * nseg * d->c_out, tg::as_stream(stream));
     if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(colsum)");
   }
-  return igemm_impl(d, 1, in, w, nullptr, out, stream, colsum, seg_rows, nseg, bf16);
+  return igemm_impl(d, 1, in, w, nullptr, out, stream, colsum, seg_rows, nseg, bf16, ymul, ymul_act, ymul_alpha);
 }
 
 extern "C" int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
@@ -792,6 +835,18 @@ extern "C" int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, cons
 extern "C" int tg_igemm_colsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
                                     double* colsum, int colsum_zeroed, void* stream) {
   return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, true);
+}
+
+extern "C" int tg_igemm_actsum_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* yact, int act, float alpha, float* out,
+                                   const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* stream) {
+  TG_REQUIRE(yact != nullptr, "igemm_actsum: yact is NULL");
+  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, false, yact, act, alpha);
+}
+
+extern "C" int tg_igemm_actsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* yact, int act, float alpha, float* out,
+                                    const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* stream) {
+  TG_REQUIRE(yact != nullptr, "igemm_actsum: yact is NULL");
+  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, true, yact, act, alpha);
 }
 
 extern "C" int tg_igemm_multi_bf16(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,

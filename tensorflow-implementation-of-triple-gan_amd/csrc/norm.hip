@@ -326,6 +326,31 @@ __global__ void __launch_bounds__(256) mobn_bwd_apply(const float* __restrict__ 
   }
 }
 
+// dx = t - mean_seg(t) given the per-segment column sums of t (single accumulator copy, written by tg_igemm_actsum_*); db = sum of sums
+__global__ void __launch_bounds__(256) mobn_center(const float* __restrict__ t, int ld_t, float* __restrict__ dx, int ld_dx, int c, SegTable st,
+                                                   const double* __restrict__ sums, float* __restrict__ db) {
+  __shared__ float shift[512];
+  int seg, r0, r1;
+  if (!bn_chunk(st, 32, blockIdx.x, &seg, &r0, &r1)) return;
+  for (int k = threadIdx.x; k < c; k += 256) shift[k] = -(float)(sums[(int64_t)seg * c + k] / (double)st.rows[seg]);
+  if (blockIdx.x == 0 && db) {
+    for (int k = threadIdx.x; k < c; k += 256) {
+      double a = 0.;
+      for (int s = 0; s < st.nseg; ++s) a += sums[(int64_t)s * c + k];
+      db[k] = (float)a;
+    }
+  }
+  __syncthreads();
+  const int c4 = c >> 2;
+  const int rows_here = r1 - r0;
+  for (int i = threadIdx.x; i < rows_here * c4; i += 256) {
+    const int rr = i / c4, cg = i - rr * c4;
+    float4 v = *reinterpret_cast<const float4*>(t + (int64_t)(r0 + rr) * ld_t + cg * 4);
+    v.x += shift[cg * 4]; v.y += shift[cg * 4 + 1]; v.z += shift[cg * 4 + 2]; v.w += shift[cg * 4 + 3];
+    *reinterpret_cast<float4*>(dx + (int64_t)(r0 + rr) * ld_dx + cg * 4) = v;
+  }
+}
+
 // dpre = dy * act'(yact) (pad columns zeroed up to ld_out) AND its column sums (the bias gradient of a plain conv / transposed conv /
 // dense layer) in one pass: per-workgroup partial sums -> one fp64 atomic per column into replica (workgroup % REPL); a second tiny
 // launch adds the replicas.  Replaces actgrad + two-stage colstats (three launches, two passes over dpre).
@@ -821,6 +846,19 @@ int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, flo
   TG_CHECK_LAUNCH("mobn_bwd_sums");
   hipLaunchKernelGGL(mobn_bwd_apply, dim3(seg_chunks(st, 32)), dim3(256), 0, s, dy, ld_dy, yact, ld_y, dx, ld_dx, rows, c, st, act, alpha, sums, db);
   TG_CHECK_LAUNCH("mobn_bwd_apply");
+  return TG_OK;
+}
+
+int tg_mobn_center_f32(const float* t, int ld_t, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg, const double* sums,
+                       float* db, void* stream) {
+  SegTable st;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(t && dx && sums && c > 0 && c <= 512 && c % 4 == 0 && ld_t % 4 == 0 && ld_dx % 4 == 0 && c <= ld_t && c <= ld_dx, "mobn_center: c=%d vs ld", c);
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 8.0 * rows * c, s);
+  hipLaunchKernelGGL(mobn_center, dim3(seg_chunks(st, 32)), dim3(256), 0, s, t, ld_t, dx, ld_dx, c, st, sums, db);
+  TG_CHECK_LAUNCH("mobn_center");
   return TG_OK;
 }
 

@@ -8,7 +8,9 @@ from . import geom, lib
 from .lib import ACT
 from .runtime import Act, ctx, pad32, seg_array
 
-_MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_wgrad_f32')
+import os as _os
+_ACTSUM = _os.environ.get('TG_ACTSUM', '1') != '0'      # A/B switch of the input-gradient + activation-derivative + column-sum fusion
+_MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_igemm_actsum_f32', 'tg_wgrad_f32')
 
 
 def _call(name, *args):
@@ -143,6 +145,8 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
 
     if not (needs_w or needs_x):
         return y
+    if mobn is not None and train and act is not None and c_out == co_p and c_out <= 512 and len(seg_rows) <= 8 and ld_out == co_p:
+        y.grad_sink = (act, alpha, tuple(seg_rows))      # see Act.grad_sink
 
     def bwd():
         gy = y.grad
@@ -155,6 +159,11 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
             dpre = cx.scratch('dpre', y.rows * co_p)
         if mobn is None and dpre is gy.t:
             pass
+        elif mobn is not None and y.grad_fused is not None:
+            # the consumer's input-gradient launch already stored t = dy*act'(y) in y.grad and summed its columns per application
+            db = mobn[1] if needs_w else cx.scratch('db', c_out)
+            _call('tg_mobn_center_f32', gy.ptr, gy.ld, _p(dpre), co_p, y.rows, c_out, seg_array(seg_rows), len(seg_rows), _p(y.grad_fused),
+                  _p(db), cx.stream)
         elif mobn is not None and c_out == co_p and c_out <= 512 and len(seg_rows) <= 8:
             db = mobn[1] if needs_w else cx.scratch('db', c_out)
             sums64, zd = cx.zscratch('bs64', 16 * len(seg_rows) * c_out)     # 8 replicas x nseg x c doubles
@@ -187,9 +196,22 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
                     coef = cx.scratch('coef', 2 * c_out)
                     _call('tg_wn_bwd_f32', _p(dw), _p(kernel), _p(wn[0]), t * c_in, c_out, _p(kernel_grad), _p(wn[1]), _p(coef), cx.stream)
         if needs_x:
+            fresh = x.grad is None
             gx = cx.grad_of(x)
-            dds = lib.desc_array(geom.conv_dgrad(x.n, x.h, x.w, ci_p, co_p, k, stride, padding, ld_out=gx.ld, n_store=ci_p))
-            _call('tg_igemm_multi_f32', C.cast(dds, C.c_void_p), len(dds), _p(dpre), _p(w_hwio), None, gx.ptr, cx.stream)
+            dlist = geom.conv_dgrad(x.n, x.h, x.w, ci_p, co_p, k, stride, padding, ld_out=gx.ld, n_store=ci_p)
+            sink = x.grad_sink
+            if (_ACTSUM and sink is not None and fresh and len(dlist) == 1 and x.c == ci_p == gx.ld == x.ld and sum(sink[2]) == x.rows
+                    and _colsum_tile_exists(ci_p, sink[2])):
+                # x is the output of a mean-only-BN layer: this launch also applies that layer's activation derivative and sums the
+                # columns per application, so its backward pass needs no statistics pass of its own (tg_mobn_center_f32)
+                nsg = len(sink[2])
+                gsum, zd = cx.zscratch('gs64', 2 * nsg * ci_p)
+                _call('tg_igemm_actsum_f32', dlist[0], _p(dpre), _p(w_hwio), x.ptr, ACT[sink[0]], sink[1], gx.ptr, seg_array(sink[2]), nsg,
+                      _p(gsum), zd, cx.stream)
+                x.grad_fused = gsum
+            else:
+                dds = lib.desc_array(dlist)
+                _call('tg_igemm_multi_f32', C.cast(dds, C.c_void_p), len(dds), _p(dpre), _p(w_hwio), None, gx.ptr, cx.stream)
 
     cx.record(bwd)
     return y

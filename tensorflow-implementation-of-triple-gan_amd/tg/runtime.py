@@ -26,13 +26,15 @@ def pad32(c):
 class Act(object):
     """Handle of an NHWC activation buffer: logical shape [n,h,w,c], channel stride ld >= c
     (channels c..ld are zero when the buffer feeds an MFMA kernel)."""
-    __slots__ = ('t', 'n', 'h', 'w', 'c', 'ld', 'grad', 'requires_grad', 'strided_grad_ok')
+    __slots__ = ('t', 'n', 'h', 'w', 'c', 'ld', 'grad', 'requires_grad', 'strided_grad_ok', 'grad_sink', 'grad_fused')
 
     def __init__(self, t, n, h, w, c, ld, requires_grad=False):
         self.t, self.n, self.h, self.w, self.c, self.ld = t, n, h, w, c, ld
         self.grad = None
         self.requires_grad = requires_grad
         self.strided_grad_ok = False      # set by producers whose backward reads .grad through (pointer, channel stride) only
+        self.grad_sink = None             # (act, alpha, seg_rows): the producer is a mean-only-BN layer — a consumer whose input-gradient
+        self.grad_fused = None            # launch can apply act'(y) and sum the columns stores t = dx*act'(y) in .grad and the sums here
 
     @property
     def rows(self):

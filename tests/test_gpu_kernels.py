@@ -343,3 +343,46 @@ def test_actgrad_with_bias_gradient(rows, c, ld_out, act):
     np.testing.assert_allclose(o[:, :c], ref, rtol=1e-6, atol=1e-6)
     assert (o[:, c:] == 0).all()
     np.testing.assert_allclose(bg.cpu().numpy(), ref.sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("prec", ['f32', 'bf16'])
+@pytest.mark.parametrize("segs,h", [([2, 4, 1], 8), ([5, 5, 9], 6)])
+def test_input_gradient_fused_with_mobn_backward_statistics(prec, segs, h):
+    """tg_igemm_actsum_* (input gradient of a conv, times act'(y) of the mean-only-BN layer that produced its input, with per-application
+    column sums) + tg_mobn_center_f32 == conv2d_bwd_input -> lrelu' -> mean_only_batch_norm backward of the oracle."""
+    from tg import geom
+    lib = _lib()
+    q = (lambda a: T.bf16_round(a)) if prec == 'bf16' else (lambda a: a)
+    rng = np.random.default_rng(9)
+    n, w_, cin, cout = sum(segs), h, 64, 96           # the differentiated conv: cin -> cout; its input is the MOBN layer's output y
+    y = rng.standard_normal((n, h, w_, cin)).astype(np.float32)          # activated output of the producing layer (sign decides lrelu')
+    wt = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
+    dpre = rng.standard_normal((n, h, w_, cout)).astype(np.float32)      # gradient at the conv's pre-activation
+    seg_rows = [s * h * w_ for s in segs]
+    sa = (C.c_int32 * len(segs))(*seg_rows)
+    gx = T.conv2d_bwd_input(y.shape, q(wt).astype(np.float64), q(dpre).astype(np.float64))
+    t_ref = T.lrelu_bwd_from_out(y.astype(np.float64), gx, 0.2)
+    dx_ref, o = [], 0
+    for s in segs:
+        dxs, _ = T.mobn_train_bwd(t_ref[o:o + s])
+        dx_ref.append(dxs)
+        o += s
+    dx_ref, db_ref = np.concatenate(dx_ref), t_ref.sum(axis=(0, 1, 2))
+    co_p = geom.pad32(cout)
+    w_hwio = np.zeros((9, cin, co_p), np.float32)
+    w_hwio[:, :, :cout] = wt.reshape(9, cin, cout)
+    dp = np.zeros((n, h, w_, co_p), np.float32)
+    dp[..., :cout] = dpre
+    yd, wd, dd = dev(y), dev(w_hwio), dev(dp)
+    td = torch.full((n, h, w_, cin), 7.0, device='cuda')
+    sums = torch.zeros(2 * len(segs) * cin, device='cuda')
+    descs = geom.conv_dgrad(n, h, w_, cin, co_p, 3, 1, 'SAME')
+    assert len(descs) == 1
+    lib.call('tg_igemm_actsum_' + prec, descs[0], lib.ptr(dd), lib.ptr(wd), lib.ptr(yd), lib.ACT['lrelu'], 0.2, lib.ptr(td), sa, len(segs),
+             lib.ptr(sums), 0, st())
+    scale = np.abs(dpre).max() * np.abs(wt).max() * 9 * cout
+    assert np.abs(td.cpu().numpy() - t_ref).max() <= 3e-5 * scale
+    dxd, dbd = torch.full((n, h, w_, cin), 7.0, device='cuda'), torch.full((cin,), 7.0, device='cuda')
+    lib.call('tg_mobn_center_f32', lib.ptr(td), cin, lib.ptr(dxd), cin, n * h * w_, cin, sa, len(segs), lib.ptr(sums), lib.ptr(dbd), st())
+    assert np.abs(dxd.cpu().numpy() - dx_ref).max() <= 3e-5 * scale
+    np.testing.assert_allclose(dbd.cpu().numpy(), db_ref, rtol=1e-4, atol=3e-5 * scale * 8)
