@@ -195,9 +195,17 @@ int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows
 int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
                     int act, float alpha, double* sums, int sums_zeroed, float* db, void* stream);
 /* second half of the mean-only-BN backward when t = dy*act'(y) and its per-segment column sums already exist (tg_igemm_actsum_f32):
- * dx = t - sums[seg]/rows_seg (dx may alias t), db[k] = sum_s sums[s][k] (db may be NULL).  sums: [nseg][c] doubles.  c <= 512, c % 4 == 0. */
+ * dx = t - sums[seg]/rows_seg (dx may alias t), db[k] = sum_s sums[s][k] (db may be NULL).  sums: n_repl copies of [nseg][c] doubles that are
+ * added up (1 after tg_igemm_actsum_f32, 8 after tg_maxpool2_bwd_actsum_f32).  c <= 512, c % 4 == 0. */
 int tg_mobn_center_f32(const float* t, int ld_t, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg, const double* sums,
-                       float* db, void* stream);
+                       int n_repl, float* db, void* stream);
+/* 2x2 max-pool (+ dropout) backward in front of a mean-only-BN layer (Model/Good_GAN_cifar10.py:123-124,142-143): t = routed pooled
+ * gradient * act'(y) written to the layer's gradient buffer and its per-application column sums accumulated in the same pass
+ * (sums: 8 replicas of [nseg][c] doubles -> tg_mobn_center_f32 with n_repl = 8).  seg_rows: HOST array in pre-pool pixel rows
+ * (whole images per application).  c <= 512, c % 4 == 0. */
+int tg_maxpool2_bwd_actsum_f32(const float* dout, int ld_do, const float* mask, int ld_mask, float mscale, const float* y, int ld_y, float* t, int ld_t,
+                               int n, int h, int w, int c, const int32_t* seg_rows, int nseg, int act, float alpha, double* sums, int sums_zeroed,
+                               void* stream);
 /* shift[s][k] = -sums[s][k]/rows_s; db[k] = sum_s sums[s][k]. */
 int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, int rows, int c, float* shift, float* db, void* stream);
 /* Fused training-mode batch norm over application segments (two launches): per segment s and column k

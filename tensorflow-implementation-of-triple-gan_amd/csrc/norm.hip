@@ -328,15 +328,20 @@ __global__ void __launch_bounds__(256) mobn_bwd_apply(const float* __restrict__ 
 
 // dx = t - mean_seg(t) given the per-segment column sums of t (single accumulator copy, written by tg_igemm_actsum_*); db = sum of sums
 __global__ void __launch_bounds__(256) mobn_center(const float* __restrict__ t, int ld_t, float* __restrict__ dx, int ld_dx, int c, SegTable st,
-                                                   const double* __restrict__ sums, float* __restrict__ db) {
+                                                   const double* __restrict__ sums, int n_repl, float* __restrict__ db) {
   __shared__ float shift[512];
   int seg, r0, r1;
   if (!bn_chunk(st, 32, blockIdx.x, &seg, &r0, &r1)) return;
-  for (int k = threadIdx.x; k < c; k += 256) shift[k] = -(float)(sums[(int64_t)seg * c + k] / (double)st.rows[seg]);
+  auto total = [&](int s, int k) {
+    double a = 0.;
+    for (int r = 0; r < n_repl; ++r) a += sums[((int64_t)r * st.nseg + s) * c + k];      // fixed order
+    return a;
+  };
+  for (int k = threadIdx.x; k < c; k += 256) shift[k] = -(float)(total(seg, k) / (double)st.rows[seg]);
   if (blockIdx.x == 0 && db) {
     for (int k = threadIdx.x; k < c; k += 256) {
       double a = 0.;
-      for (int s = 0; s < st.nseg; ++s) a += sums[(int64_t)s * c + k];
+      for (int s = 0; s < st.nseg; ++s) a += total(s, k);
       db[k] = (float)a;
     }
   }
@@ -348,6 +353,67 @@ __global__ void __launch_bounds__(256) mobn_center(const float* __restrict__ t, 
     float4 v = *reinterpret_cast<const float4*>(t + (int64_t)(r0 + rr) * ld_t + cg * 4);
     v.x += shift[cg * 4]; v.y += shift[cg * 4 + 1]; v.z += shift[cg * 4 + 2]; v.w += shift[cg * 4 + 3];
     *reinterpret_cast<float4*>(dx + (int64_t)(r0 + rr) * ld_dx + cg * 4) = v;
+  }
+}
+
+// 2x2 max-pool (+ dropout) backward whose result feeds a mean-only-BN layer: routes the pooled gradient to the arg-max position,
+// multiplies by act'(y) and accumulates the per-application column sums of the product t — the statistics pass of that layer's
+// backward — in the same pass.  Work unit: pooled pixels; `st` holds the application sizes in POOLED pixels.
+__global__ void __launch_bounds__(256) maxpool2_bwd_actsum(const float* __restrict__ dout, int ld_do, const float* __restrict__ mask, int ld_m,
+                                                           float mscale, const float* __restrict__ y, int ld_y, float* __restrict__ t, int ld_t,
+                                                           int h, int w, int c, SegTable st, int chunk, int act, float alpha,
+                                                           double* __restrict__ sums) {
+  int seg, r0, r1;
+  if (!bn_chunk(st, chunk, blockIdx.x, &seg, &r0, &r1)) return;
+  const int ho = h >> 1, wo = w >> 1;
+  const int c4 = c >> 2;
+  const int lanes = 256 / c4 > 0 ? 256 / c4 : 1;
+  const int cg = threadIdx.x % c4, rl = threadIdx.x / c4;
+  __shared__ float4 red[256];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (rl < lanes) {
+    for (int pp = r0 + rl; pp < r1; pp += lanes) {
+      const int ox = pp % wo, oy = (pp / wo) % ho, img = pp / (wo * ho);
+      const int64_t base = ((int64_t)img * h + 2 * oy) * w + 2 * ox;
+      const int64_t pos[4] = {base, base + 1, base + w, base + w + 1};
+      float yv[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(y + pos[q] * ld_y + cg * 4);
+        yv[q][0] = v.x; yv[q][1] = v.y; yv[q][2] = v.z; yv[q][3] = v.w;
+      }
+      const float4 gv = *reinterpret_cast<const float4*>(dout + (int64_t)pp * ld_do + cg * 4);
+      float g[4] = {gv.x, gv.y, gv.z, gv.w};
+      if (mask) {
+        const float4 m = *reinterpret_cast<const float4*>(mask + (int64_t)pp * ld_m + cg * 4);
+        g[0] *= m.x * mscale; g[1] *= m.y * mscale; g[2] *= m.z * mscale; g[3] *= m.w * mscale;
+      }
+      float o[4][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int am = 0;
+        float mv = yv[0][e];
+        if (yv[1][e] > mv) { mv = yv[1][e]; am = 1; }
+        if (yv[2][e] > mv) { mv = yv[2][e]; am = 2; }
+        if (yv[3][e] > mv) { mv = yv[3][e]; am = 3; }
+        const float tv = g[e] * tgd::act_grad(mv, act, alpha);
+        acc[e] += tv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q][e] = q == am ? tv : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(t + pos[q] * ld_t + cg * 4) = make_float4(o[q][0], o[q][1], o[q][2], o[q][3]);
+    }
+  }
+  red[threadIdx.x] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < lanes; ++k) {
+      const float4 v = red[k * c4 + cg];
+      acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+    }
+    double* o = sums + ((int64_t)(blockIdx.x % REPL) * st.nseg + seg) * c + cg * 4;
+    atomicAdd(o, (double)acc[0]); atomicAdd(o + 1, (double)acc[1]); atomicAdd(o + 2, (double)acc[2]); atomicAdd(o + 3, (double)acc[3]);
   }
 }
 
@@ -850,15 +916,39 @@ int tg_mobn_bwd_f32(const float* dy, int ld_dy, const float* yact, int ld_y, flo
 }
 
 int tg_mobn_center_f32(const float* t, int ld_t, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg, const double* sums,
-                       float* db, void* stream) {
+                       int n_repl, float* db, void* stream) {
   SegTable st;
   int rc = make_segs(st, seg_rows, nseg, rows);
   if (rc != TG_OK) return rc;
   TG_REQUIRE(t && dx && sums && c > 0 && c <= 512 && c % 4 == 0 && ld_t % 4 == 0 && ld_dx % 4 == 0 && c <= ld_t && c <= ld_dx, "mobn_center: c=%d vs ld", c);
+  TG_REQUIRE(n_repl == 1 || n_repl == REPL, "mobn_center: n_repl=%d (1 or %d)", n_repl, REPL);
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_NORM, 0, 8.0 * rows * c, s);
-  hipLaunchKernelGGL(mobn_center, dim3(seg_chunks(st, 32)), dim3(256), 0, s, t, ld_t, dx, ld_dx, c, st, sums, db);
+  hipLaunchKernelGGL(mobn_center, dim3(seg_chunks(st, 32)), dim3(256), 0, s, t, ld_t, dx, ld_dx, c, st, sums, n_repl, db);
   TG_CHECK_LAUNCH("mobn_center");
+  return TG_OK;
+}
+
+int tg_maxpool2_bwd_actsum_f32(const float* dout, int ld_do, const float* mask, int ld_mask, float mscale, const float* y, int ld_y, float* t, int ld_t,
+                               int n, int h, int w, int c, const int32_t* seg_rows, int nseg, int act, float alpha, double* sums, int sums_zeroed,
+                               void* stream) {
+  TG_REQUIRE(dout && y && t && sums && n > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "maxpool2_bwd_actsum: bad args");
+  TG_REQUIRE(c > 0 && c <= 512 && c % 4 == 0 && ld_do % 4 == 0 && ld_y % 4 == 0 && ld_t % 4 == 0 && (!mask || ld_mask % 4 == 0) && c <= ld_do &&
+             c <= ld_y && c <= ld_t, "maxpool2_bwd_actsum: c=%d vs ld", c);
+  SegTable st;                                           // given in pre-pool pixel rows (the layer's output rows) -> pooled pixels
+  int rc = make_segs(st, seg_rows, nseg, n * h * w);
+  if (rc != TG_OK) return rc;
+  for (int i = 0; i < nseg; ++i) { TG_REQUIRE(st.rows[i] % (h * w) == 0, "maxpool2_bwd_actsum: segment %d is not whole images", i); st.rows[i] /= 4; }
+  hipStream_t s = tg::as_stream(stream);
+  if (!sums_zeroed) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * REPL * nseg * c, s);
+    if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(maxpool2_bwd_actsum sums)");
+  }
+  tg::ProfScope prof(tg::PC_ELEMWISE, 0, 4.0 * n * h * w * c * 2.5, s);
+  const int chunk = stats_chunk(st);
+  hipLaunchKernelGGL(maxpool2_bwd_actsum, dim3(seg_chunks(st, chunk)), dim3(256), 0, s, dout, ld_do, mask, ld_mask, mscale, y, ld_y, t, ld_t, h, w, c, st,
+                     chunk, act, alpha, sums);
+  TG_CHECK_LAUNCH("maxpool2_bwd_actsum");
   return TG_OK;
 }
 

@@ -162,8 +162,8 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
         elif mobn is not None and y.grad_fused is not None:
             # the consumer's input-gradient launch already stored t = dy*act'(y) in y.grad and summed its columns per application
             db = mobn[1] if needs_w else cx.scratch('db', c_out)
-            _call('tg_mobn_center_f32', gy.ptr, gy.ld, _p(dpre), co_p, y.rows, c_out, seg_array(seg_rows), len(seg_rows), _p(y.grad_fused),
-                  _p(db), cx.stream)
+            _call('tg_mobn_center_f32', gy.ptr, gy.ld, _p(dpre), co_p, y.rows, c_out, seg_array(seg_rows), len(seg_rows), _p(y.grad_fused[0]),
+                  y.grad_fused[1], _p(db), cx.stream)
         elif mobn is not None and c_out == co_p and c_out <= 512 and len(seg_rows) <= 8:
             db = mobn[1] if needs_w else cx.scratch('db', c_out)
             sums64, zd = cx.zscratch('bs64', 16 * len(seg_rows) * c_out)     # 8 replicas x nseg x c doubles
@@ -208,7 +208,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
                 gsum, zd = cx.zscratch('gs64', 2 * nsg * ci_p)
                 _call('tg_igemm_actsum_f32', dlist[0], _p(dpre), _p(w_hwio), x.ptr, ACT[sink[0]], sink[1], gx.ptr, seg_array(sink[2]), nsg,
                       _p(gsum), zd, cx.stream)
-                x.grad_fused = gsum
+                x.grad_fused = (gsum, 1)
             else:
                 dds = lib.desc_array(dlist)
                 _call('tg_igemm_multi_f32', C.cast(dds, C.c_void_p), len(dds), _p(dpre), _p(w_hwio), None, gx.ptr, cx.stream)
@@ -433,9 +433,20 @@ def maxpool2_dropout(y, mask_t, mscale):
     _call('tg_maxpool2_fwd_f32', y.ptr, y.ld, out.ptr, out.ld, _p(mask_t), y.c, mscale, y.n, y.h, y.w, y.c, cx.stream)
     if cx.tape is not None and y.requires_grad:
         def bwd():
+            fresh = y.grad is None
             gy = cx.grad_of(y)
-            _call('tg_maxpool2_bwd_f32', out.grad.ptr, out.grad.ld, _p(mask_t), y.c, mscale, y.ptr, y.ld, gy.ptr, gy.ld, y.n, y.h, y.w,
-                  y.c, cx.stream)
+            sink = y.grad_sink
+            if (_ACTSUM and sink is not None and fresh and y.c % 4 == 0 and y.c <= 512 and sum(sink[2]) == y.rows
+                    and all(r % (y.h * y.w) == 0 for r in sink[2])):
+                # y is the output of a mean-only-BN layer: route, multiply by its activation derivative and sum the columns in one pass
+                nsg = len(sink[2])
+                gsum, zd = cx.zscratch('ps64', 16 * nsg * y.c)
+                _call('tg_maxpool2_bwd_actsum_f32', out.grad.ptr, out.grad.ld, _p(mask_t), y.c, mscale, y.ptr, y.ld, gy.ptr, gy.ld, y.n, y.h, y.w,
+                      y.c, seg_array(sink[2]), nsg, ACT[sink[0]], sink[1], _p(gsum), zd, cx.stream)
+                y.grad_fused = (gsum, 8)
+            else:
+                _call('tg_maxpool2_bwd_f32', out.grad.ptr, out.grad.ld, _p(mask_t), y.c, mscale, y.ptr, y.ld, gy.ptr, gy.ld, y.n, y.h, y.w,
+                      y.c, cx.stream)
         cx.record(bwd)
     return out
 

@@ -383,6 +383,39 @@ def test_input_gradient_fused_with_mobn_backward_statistics(prec, segs, h):
     scale = np.abs(dpre).max() * np.abs(wt).max() * 9 * cout
     assert np.abs(td.cpu().numpy() - t_ref).max() <= 3e-5 * scale
     dxd, dbd = torch.full((n, h, w_, cin), 7.0, device='cuda'), torch.full((cin,), 7.0, device='cuda')
-    lib.call('tg_mobn_center_f32', lib.ptr(td), cin, lib.ptr(dxd), cin, n * h * w_, cin, sa, len(segs), lib.ptr(sums), lib.ptr(dbd), st())
+    lib.call('tg_mobn_center_f32', lib.ptr(td), cin, lib.ptr(dxd), cin, n * h * w_, cin, sa, len(segs), lib.ptr(sums), 1, lib.ptr(dbd), st())
     assert np.abs(dxd.cpu().numpy() - dx_ref).max() <= 3e-5 * scale
     np.testing.assert_allclose(dbd.cpu().numpy(), db_ref, rtol=1e-4, atol=3e-5 * scale * 8)
+
+
+def test_maxpool_backward_fused_with_mobn_backward_statistics():
+    """tg_maxpool2_bwd_actsum_f32 + tg_mobn_center_f32 (8 accumulator replicas) == max-pool/dropout backward -> lrelu' -> mean-only-BN
+    backward of the oracle, per application segment."""
+    lib = _lib()
+    rng = np.random.default_rng(12)
+    segs, h, c = [3, 1, 2], 8, 64
+    n = sum(segs)
+    y = rng.standard_normal((n, h, h, c)).astype(np.float32)
+    dpool = rng.standard_normal((n, h // 2, h // 2, c)).astype(np.float32)
+    mask = (rng.random(dpool.shape) < 0.5).astype(np.float32)
+    _, idx = T.maxpool2(y.astype(np.float64))
+    gy = T.maxpool2_bwd((dpool * mask * 2.0).astype(np.float64), idx, y.shape)
+    t_ref = T.lrelu_bwd_from_out(y.astype(np.float64), gy, 0.2)
+    dx_ref, o = [], 0
+    for s in segs:
+        dxs, _ = T.mobn_train_bwd(t_ref[o:o + s])
+        dx_ref.append(dxs)
+        o += s
+    dx_ref = np.concatenate(dx_ref)
+    seg_rows = [s * h * h for s in segs]
+    sa = (C.c_int32 * len(segs))(*seg_rows)
+    yd, dd, md = dev(y), dev(dpool), dev(mask)
+    td = torch.full((n, h, h, c), 7.0, device='cuda')
+    sums = torch.zeros(16 * len(segs) * c, device='cuda')
+    lib.call('tg_maxpool2_bwd_actsum_f32', lib.ptr(dd), c, lib.ptr(md), c, 2.0, lib.ptr(yd), c, lib.ptr(td), c, n, h, h, c, sa, len(segs),
+             lib.ACT['lrelu'], 0.2, lib.ptr(sums), 0, st())
+    np.testing.assert_allclose(td.cpu().numpy(), t_ref, rtol=1e-6, atol=1e-6)
+    dxd, dbd = torch.full((n, h, h, c), 7.0, device='cuda'), torch.full((c,), 7.0, device='cuda')
+    lib.call('tg_mobn_center_f32', lib.ptr(td), c, lib.ptr(dxd), c, n * h * h, c, sa, len(segs), lib.ptr(sums), 8, lib.ptr(dbd), st())
+    np.testing.assert_allclose(dxd.cpu().numpy(), dx_ref, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(dbd.cpu().numpy(), t_ref.sum(axis=(0, 1, 2)), rtol=1e-5, atol=1e-4)
