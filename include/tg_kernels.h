@@ -156,6 +156,21 @@ int tg_wn_bwd_tab_f32(const float* dw, const float* v, const float* g, int t, in
  * w: [25][c_out][c_in] (tf conv2d_transpose filter [kh,kw,Cout,Cin]); tapmap: HOST array of 36 entries. */
 int tg_deconv_merge_prep_f32(const float* w, const float* scale_a, int c_out, int c_in, int n_group, int n_pad, int c_pad,
                              const int32_t* tapmap, float* dst, void* stream);
+/* The tails of up to 16 filter-gradient launches in three launches instead of up to three each: for every job
+ *   dw[t][c_in][c_out] = sum_s slab[s][t][c_pad][n_pad]                                  (as tg_slab_reduce_f32)
+ *   and, when v != NULL (weight-normalised layer), dv / dg from dw as tg_wn_bwd_f32 (rows = t*c_in).
+ * Jobs without v write dw as the final gradient.  coef: scratch of 2*c_out floats per weight-normalised job. */
+typedef struct tg_wn_job {
+  const float* slab;
+  float* dw;
+  const float* v;
+  const float* g;
+  float* dv;
+  float* dg;
+  float* coef;
+  int32_t n_split, t, c_pad, n_pad, c_in, c_out;
+} tg_wn_job;
+int tg_filter_grad_tail_multi_f32(const tg_wn_job* jobs, int n_jobs, void* stream);
 /* dst[t][c][n] = sum_s slab[s][t][c][n] (c < c_dim, n < n_dim): finishes tg_wgrad_f32, drops channel padding. */
 int tg_slab_reduce_f32(const float* slab, int n_split, int t, int c_pad, int n_pad, int c_dim, int n_dim, float* dst, void* stream);
 

@@ -74,6 +74,65 @@ __global__ void __launch_bounds__(256) wn_bwd_apply(const float* __restrict__ dw
   }
 }
 
+constexpr int MAX_WN_JOBS = 16;
+struct WnJobs { tg_wn_job j[MAX_WN_JOBS]; };
+
+// blockIdx.y = job
+__global__ void __launch_bounds__(256) slab_reduce_multi(WnJobs js) {
+  const tg_wn_job& J = js.j[blockIdx.y];
+  const int64_t total = (int64_t)J.t * J.c_in * J.c_out;
+  const int64_t sstride = (int64_t)J.t * J.c_pad * J.n_pad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % J.c_out);
+    const int64_t tc = i / J.c_out;
+    const int c = (int)(tc % J.c_in), t = (int)(tc / J.c_in);
+    const float* p = J.slab + ((int64_t)t * J.c_pad + c) * J.n_pad + n;
+    float acc = 0.f;
+    for (int s = 0; s < J.n_split; ++s) acc += p[s * sstride];
+    J.dw[i] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(1024) wn_bwd_cols_multi(WnJobs js) {
+  const tg_wn_job& J = js.j[blockIdx.y];
+  if (J.v == nullptr) return;
+  const int r = J.t * J.c_in, c = J.c_out;
+  if (blockIdx.x * 32 >= c) return;
+  const int tx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + tx;
+  float d0 = 0.f, s0 = 0.f;
+  if (col < c) {
+    for (int i = ry; i < r; i += 32) {
+      const float t = J.v[(int64_t)i * c + col];
+      d0 += J.dw[(int64_t)i * c + col] * t;
+      s0 += t * t;
+    }
+  }
+  __shared__ float red[2][32][33];
+  red[0][ry][tx] = d0;
+  red[1][ry][tx] = s0;
+  __syncthreads();
+  if (ry == 0 && col < c) {
+    float dot = d0, ss = s0;
+    for (int k = 1; k < 32; ++k) { dot += red[0][k][tx]; ss += red[1][k][tx]; }
+    const float nrm = sqrtf(ss);
+    J.dg[col] = dot / nrm;
+    J.coef[col] = J.g[col] / nrm;
+    J.coef[c + col] = dot / ss;
+  }
+}
+
+__global__ void __launch_bounds__(256) wn_bwd_apply_multi(WnJobs js) {
+  const tg_wn_job& J = js.j[blockIdx.y];
+  if (J.v == nullptr) return;
+  const int c = J.c_out;
+  const int64_t n = (int64_t)J.t * J.c_in * c;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % c);
+    J.dv[i] = J.coef[col] * (J.dw[i] - J.v[i] * J.coef[c + col]);
+  }
+}
+
 // src [T][A][B] (B contiguous), optional per-b scale.
 //   dst_same[t][a][b]      padded copy  [T][A_pad][B_pad]
 //   dst_tr  [b*sb + t*st + a]           (a contiguous; rows b < B_pad, a < A_pad, zero padded)
@@ -256,6 +315,40 @@ int tg_deconv_merge_prep_f32(const float* w, const float* scale_a, int c_out, in
   tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * (total + 25.0 * c_out * c_in), s);
   hipLaunchKernelGGL(deconv_merge_prep, dim3(ew_grid(total)), dim3(256), 0, s, w, scale_a, c_out, c_in, n_group, n_pad, c_pad, tm, dst);
   TG_CHECK_LAUNCH("deconv_merge_prep");
+  return TG_OK;
+}
+
+int tg_filter_grad_tail_multi_f32(const tg_wn_job* jobs, int n_jobs, void* stream) {
+  TG_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= MAX_WN_JOBS, "filter_grad_tail_multi: n_jobs=%d out of range", n_jobs);
+  WnJobs js;
+  int64_t max_total = 0;
+  int max_c = 0;
+  bool any_wn = false;
+  double bytes = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const tg_wn_job& j = jobs[i];
+    TG_REQUIRE(j.slab && j.dw && j.n_split >= 1 && j.t >= 1 && j.c_in >= 1 && j.c_out >= 1 && j.c_in <= j.c_pad && j.c_out <= j.n_pad,
+               "filter_grad_tail_multi: job %d has bad geometry", i);
+    TG_REQUIRE(j.v == nullptr || (j.g && j.dv && j.dg && j.coef), "filter_grad_tail_multi: job %d lacks weight-norm buffers", i);
+    js.j[i] = j;
+    const int64_t total = (int64_t)j.t * j.c_in * j.c_out;
+    max_total = total > max_total ? total : max_total;
+    max_c = j.c_out > max_c ? j.c_out : max_c;
+    any_wn = any_wn || j.v != nullptr;
+    bytes += 4.0 * total * (j.n_split + 1 + (j.v ? 5 : 0));
+  }
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_PREP, 0, bytes, s);
+  int gx = (int)((max_total + 255) / 256);
+  gx = gx > 1024 ? 1024 : gx;
+  hipLaunchKernelGGL(slab_reduce_multi, dim3(gx, n_jobs), dim3(256), 0, s, js);
+  TG_CHECK_LAUNCH("slab_reduce_multi");
+  if (any_wn) {
+    hipLaunchKernelGGL(wn_bwd_cols_multi, dim3((max_c + 31) / 32, n_jobs), dim3(1024), 0, s, js);
+    TG_CHECK_LAUNCH("wn_bwd_cols_multi");
+    hipLaunchKernelGGL(wn_bwd_apply_multi, dim3(gx, n_jobs), dim3(256), 0, s, js);
+    TG_CHECK_LAUNCH("wn_bwd_apply_multi");
+  }
   return TG_OK;
 }
 

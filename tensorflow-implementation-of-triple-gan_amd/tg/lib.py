@@ -28,6 +28,13 @@ class IgemmDesc(C.Structure):
     ]
 
 
+class WnJob(C.Structure):
+    """tg_wn_job: one filter-gradient tail (slab reduction [+ weight-norm gradient]) of tg_filter_grad_tail_multi_f32."""
+    _fields_ = [("slab", C.c_void_p), ("dw", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p), ("dv", C.c_void_p), ("dg", C.c_void_p),
+                ("coef", C.c_void_p), ("n_split", C.c_int32), ("t", C.c_int32), ("c_pad", C.c_int32), ("n_pad", C.c_int32),
+                ("c_in", C.c_int32), ("c_out", C.c_int32)]
+
+
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "tg_kernels.h")
 
 _SCALARS = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint32_t": C.c_uint32, "float": C.c_float}

@@ -68,15 +68,30 @@ def wgrad_splits(desc, m):
     return max(1, min(512 // tiles, m // 128))
 
 
-def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst):
-    """dst[t][c_dim][n_dim] = filter gradient via tg_wgrad_f32 slabs + deterministic reduce."""
+def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst, wn=None, defer=True):
+    """dst[t][c_dim][n_dim] = filter gradient via tg_wgrad_f32 slabs + deterministic reduce.
+    wn=(v, g, dv, dg): weight-normalised layer — dst is the gradient of the effective filter (scratch), dv / dg the variables'.
+    The tail (slab reduction [+ weight-norm gradient]) is DEFERRED to Context.flush_tails (end of the backward pass / bucket
+    boundary), where the tails of all layers go out as three launches; the 512-split first convolution keeps its own reduce."""
     cx = ctx()
     m = desc.n_img * desc.h_v * desc.w_v
     ns = wgrad_splits(desc, m)
     slab = cx.scratch('slab', ns * t * desc.ld_in * desc.c_out)
     _call('tg_wgrad_f32', desc, _p(in_act_t), _p(dout_t), _p(slab), ns, cx.stream)
+    deferred = defer and (cx.tape is not None or cx._phase_depth > 0)
+    wide = ns >= 32 and t * c_dim * n_dim <= 65536
+    if deferred and not wide:
+        coef = cx.scratch('coef', 2 * n_dim) if wn is not None else None
+        j = lib.WnJob(slab.data_ptr(), dst.data_ptr(), wn[0].data_ptr() if wn else None, wn[1].data_ptr() if wn else None,
+                      wn[2].data_ptr() if wn else None, wn[3].data_ptr() if wn else None, coef.data_ptr() if wn else None,
+                      ns, t, desc.ld_in, desc.c_out, c_dim, n_dim)
+        cx.tail_jobs.append(j)
+        return
     with cx.on_side(after_main=True):              # nothing on the main stream consumes dst before the phase's join
         _call('tg_slab_reduce_f32', _p(slab), ns, t, desc.ld_in, desc.c_out, c_dim, n_dim, _p(dst), cx.stream)
+        if wn is not None:
+            coef = cx.scratch('coef', 2 * n_dim)
+            _call('tg_wn_bwd_f32', _p(dst), _p(wn[0]), _p(wn[1]), t * c_dim, n_dim, _p(wn[2]), _p(wn[3]), _p(coef), cx.stream)
 
 
 # ------------------------------------------------------------------ conv / dense (plain and weight-normalised)
@@ -191,10 +206,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
                 filter_grad(dw_desc, x.t, dpre, t, c_in, c_out, kernel_grad)
             else:
                 dw = cx.scratch('dw', t * c_in * c_out)
-                filter_grad(dw_desc, x.t, dpre, t, c_in, c_out, dw)
-                with cx.on_side():                 # behind the slab reduce, in side-stream order
-                    coef = cx.scratch('coef', 2 * c_out)
-                    _call('tg_wn_bwd_f32', _p(dw), _p(kernel), _p(wn[0]), t * c_in, c_out, _p(kernel_grad), _p(wn[1]), _p(coef), cx.stream)
+                filter_grad(dw_desc, x.t, dpre, t, c_in, c_out, dw, wn=(kernel, wn[0], kernel_grad, wn[1]))
         if needs_x:
             fresh = x.grad is None
             gx = cx.grad_of(x)
@@ -275,7 +287,7 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
                 filter_grad(geom.deconv_wgrad(x.n, x.h, x.w, co_p, ci_p), dpre, x.t, 25, c_out, c_in, kernel_grad)
             else:
                 dw = cx.scratch('dw', 25 * c_out * c_in)
-                filter_grad(geom.deconv_wgrad(x.n, x.h, x.w, co_p, ci_p), dpre, x.t, 25, c_out, c_in, dw)
+                filter_grad(geom.deconv_wgrad(x.n, x.h, x.w, co_p, ci_p), dpre, x.t, 25, c_out, c_in, dw, defer=False)   # consumed right below
                 with cx.on_side():
                     _call('tg_wn_bwd_tab_f32', _p(dw), _p(kernel), _p(wn[0]), 25, c_out, c_in, _p(kernel_grad), _p(wn[1]), cx.stream)
         if needs_x:

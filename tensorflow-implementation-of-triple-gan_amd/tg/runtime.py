@@ -209,6 +209,7 @@ class Context(object):
         self.side_forward = mode == '1'
         # fp64 statistics accumulators (fused mean-only BN / batch norm) of one solver run live in ONE arena per phase, zeroed by one
         # launch at the start of the phase instead of one memset per layer and direction (36 -> 3 launches per iteration)
+        self.tail_jobs = []            # deferred filter-gradient tails of the running backward pass (ops.filter_grad / flush_tails)
         self.prep_cache = None         # {layout key: prepared filter buffers} while Train.train_iteration runs (see ops.conv2d)
         self._zarena = {}              # phase -> dict(sizes=[...], buf=tensor or None, cursor=int, recording=bool)
         self._events = {}
@@ -401,6 +402,7 @@ class Context(object):
             if fn is not BUCKET_BOUNDARY:
                 fn()
         del tape[:]
+        self.flush_tails()
 
     @contextlib.contextmanager
     def variable_scope(self, name):
@@ -464,10 +466,23 @@ class Context(object):
             fn = tape[i]
             if fn is BUCKET_BOUNDARY:
                 if stop_at_boundary:
+                    self.flush_tails()             # the finished bucket's gradients must be complete
                     return tape[:i]
                 continue
             fn()
+        self.flush_tails()
         return None
+
+    def flush_tails(self):
+        """launch the deferred filter-gradient tails (slab reduction, weight-norm gradient) of the layers whose wgrad has been
+        issued since the last flush: three launches for up to 16 layers (tg_filter_grad_tail_multi_f32)."""
+        jobs, self.tail_jobs = getattr(self, 'tail_jobs', []), []
+        if not jobs:
+            return
+        for k in range(0, len(jobs), 16):
+            part = jobs[k:k + 16]
+            arr = (lib.WnJob * len(part))(*part)
+            lib.call('tg_filter_grad_tail_multi_f32', C.cast(arr, C.c_void_p), len(part), self.stream)
 
 
 BUCKET_BOUNDARY = object()
