@@ -156,6 +156,18 @@ int tg_wn_bwd_tab_f32(const float* dw, const float* v, const float* g, int t, in
  * w: [25][c_out][c_in] (tf conv2d_transpose filter [kh,kw,Cout,Cin]); tapmap: HOST array of 36 entries. */
 int tg_deconv_merge_prep_f32(const float* w, const float* scale_a, int c_out, int c_in, int n_group, int n_pad, int c_pad,
                              const int32_t* tapmap, float* dst, void* stream);
+/* tg_wn_scale_f32 + tg_filter_prep_f32 of up to 24 layers in two launches (one when no layer is weight-normalised): for every job
+ * the arguments of those two calls (g == NULL: no weight norm; scale: scratch of b floats for the weight-normalised ones). */
+typedef struct tg_prep_job {
+  const float* src;
+  const float* g;
+  float* scale;
+  float* dst_same;
+  float* dst_tr;
+  int64_t tr_sb, tr_st;
+  int32_t t, a, b, a_pad, b_pad;
+} tg_prep_job;
+int tg_filter_prep_multi_f32(const tg_prep_job* jobs, int n_jobs, void* stream);
 /* The tails of up to 16 filter-gradient launches in three launches instead of up to three each: for every job
  *   dw[t][c_in][c_out] = sum_s slab[s][t][c_pad][n_pad]                                  (as tg_slab_reduce_f32)
  *   and, when v != NULL (weight-normalised layer), dv / dg from dw as tg_wn_bwd_f32 (rows = t*c_in).

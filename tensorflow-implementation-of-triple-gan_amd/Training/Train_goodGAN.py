@@ -53,6 +53,7 @@ class Train(Train_base):
         self.model = None
         self._graphs = None
         self._warm = False
+        self._warm_keys = set()
         self.iteration = 0
         self.summary_train = self.summary_val = None
         if getattr(config, 'SUMMARY', False) and log_dir and self.rank == 0:          # :37-41
@@ -236,13 +237,14 @@ class Train(Train_base):
         graphs = self._graphs.setdefault(key, [None] * len(segs))
         pending = []
         cx.prep_cache = {}                              # filter layouts stay valid between a network's optimiser steps
+        cx.plan_tag = key
         try:
             for i, (fn, grads, overlap) in enumerate(segs):
                 if grads is None:                           # the classifier's optimiser step: needs every bucket
                     for wk in pending:
                         tgdist.wait_(wk)
                     pending = []
-                if use_graph and self._warm:
+                if use_graph and key in self._warm_keys:
                     if graphs[i] is None:
                         import ctypes as C
                         lib.call('tg_graph_begin_capture', cx.stream)
@@ -263,6 +265,7 @@ class Train(Train_base):
         finally:
             cx.prep_cache = None
         self._warm = True
+        self._warm_keys.add(key)       # graphs of a mode are captured from its SECOND iteration on: the first one allocates its buffers eagerly
         self.iteration += 1
 
     def losses(self):

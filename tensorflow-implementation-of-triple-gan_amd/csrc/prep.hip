@@ -74,6 +74,71 @@ __global__ void __launch_bounds__(256) wn_bwd_apply(const float* __restrict__ dw
   }
 }
 
+constexpr int MAX_PREP_JOBS = 24;
+struct PrepJobs { tg_prep_job j[MAX_PREP_JOBS]; int first_block[MAX_PREP_JOBS + 1]; int n; };
+
+// scale[c] = g[c] / ||V[:,c]||  (rows = t*a), blockIdx.y = job
+__global__ void __launch_bounds__(1024) wn_scale_multi(PrepJobs js) {
+  const tg_prep_job& J = js.j[blockIdx.y];
+  if (J.g == nullptr) return;
+  const int r = J.t * J.a, c = J.b;
+  if (blockIdx.x * 32 >= c) return;
+  const int tx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + tx;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;                 // same summation order as wn_scale: both paths give identical bits
+  const float* v = J.src;
+  if (col < c) {
+    int i = ry;
+    for (; i + 96 < r; i += 128) {
+      const float t0 = v[(int64_t)i * c + col], t1 = v[(int64_t)(i + 32) * c + col], t2 = v[(int64_t)(i + 64) * c + col],
+                  t3 = v[(int64_t)(i + 96) * c + col];
+      a0 += t0 * t0; a1 += t1 * t1; a2 += t2 * t2; a3 += t3 * t3;
+    }
+    for (; i < r; i += 32) { const float t = v[(int64_t)i * c + col]; a0 += t * t; }
+  }
+  float acc = (a0 + a1) + (a2 + a3);
+  __shared__ float red[32][33];
+  red[ry][tx] = acc;
+  __syncthreads();
+  if (ry == 0 && col < c) {
+    for (int k = 1; k < 32; ++k) acc += red[k][tx];
+    J.scale[col] = J.g[col] * rsqrtf(fmaxf(acc, 1e-12f));
+  }
+}
+
+// filter_prep for every job; workgroup -> (job, t, a-tile, b-tile) through the first_block prefix table
+__global__ void __launch_bounds__(256) filter_prep_multi(PrepJobs js) {
+  __shared__ float tile[32][33];
+  int job = 0;
+  while (job + 1 < js.n && (int)blockIdx.x >= js.first_block[job + 1]) ++job;
+  const tg_prep_job& J = js.j[job];
+  int rem = blockIdx.x - js.first_block[job];
+  const int at = (J.a_pad + 31) / 32, bt = (J.b_pad + 31) / 32;
+  const int ai = rem % at; rem /= at;
+  const int bi = rem % bt;
+  const int t = rem / bt;
+  const int a0 = ai * 32, b0 = bi * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* scale = J.g ? J.scale : nullptr;
+  for (int i = ty; i < 32; i += 8) {
+    const int a = a0 + i, b = b0 + tx;
+    float v = 0.f;
+    if (a < J.a && b < J.b) {
+      v = J.src[((int64_t)t * J.a + a) * J.b + b];
+      if (scale) v *= scale[b];
+    }
+    tile[i][tx] = v;
+    if (J.dst_same && a < J.a_pad && b < J.b_pad) J.dst_same[((int64_t)t * J.a_pad + a) * J.b_pad + b] = v;
+  }
+  __syncthreads();
+  if (J.dst_tr) {
+    for (int i = ty; i < 32; i += 8) {
+      const int b = b0 + i, a = a0 + tx;
+      if (b < J.b_pad && a < J.a_pad) J.dst_tr[(int64_t)b * J.tr_sb + (int64_t)t * J.tr_st + a] = tile[tx][i];
+    }
+  }
+}
+
 constexpr int MAX_WN_JOBS = 16;
 struct WnJobs { tg_wn_job j[MAX_WN_JOBS]; };
 
@@ -315,6 +380,36 @@ int tg_deconv_merge_prep_f32(const float* w, const float* scale_a, int c_out, in
   tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * (total + 25.0 * c_out * c_in), s);
   hipLaunchKernelGGL(deconv_merge_prep, dim3(ew_grid(total)), dim3(256), 0, s, w, scale_a, c_out, c_in, n_group, n_pad, c_pad, tm, dst);
   TG_CHECK_LAUNCH("deconv_merge_prep");
+  return TG_OK;
+}
+
+int tg_filter_prep_multi_f32(const tg_prep_job* jobs, int n_jobs, void* stream) {
+  TG_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= MAX_PREP_JOBS, "filter_prep_multi: n_jobs=%d out of range", n_jobs);
+  PrepJobs js;
+  js.n = n_jobs;
+  int blocks = 0, max_b = 0;
+  bool any_wn = false;
+  double bytes = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const tg_prep_job& j = jobs[i];
+    TG_REQUIRE(j.src && (j.dst_same || j.dst_tr) && j.t > 0 && j.a > 0 && j.b > 0 && j.a_pad >= j.a && j.b_pad >= j.b, "filter_prep_multi: job %d bad", i);
+    TG_REQUIRE(j.g == nullptr || j.scale != nullptr, "filter_prep_multi: job %d is weight-normalised but has no scale buffer", i);
+    js.j[i] = j;
+    js.first_block[i] = blocks;
+    blocks += ((j.a_pad + 31) / 32) * ((j.b_pad + 31) / 32) * j.t;
+    max_b = j.b > max_b ? j.b : max_b;
+    any_wn = any_wn || j.g != nullptr;
+    bytes += 4.0 * j.t * ((double)j.a * j.b * (j.g ? 2 : 1) + (double)j.a_pad * j.b_pad * ((j.dst_same ? 1 : 0) + (j.dst_tr ? 1 : 0)));
+  }
+  js.first_block[n_jobs] = blocks;
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_PREP, 0, bytes, s);
+  if (any_wn) {
+    hipLaunchKernelGGL(wn_scale_multi, dim3((max_b + 31) / 32, n_jobs), dim3(1024), 0, s, js);
+    TG_CHECK_LAUNCH("wn_scale_multi");
+  }
+  hipLaunchKernelGGL(filter_prep_multi, dim3(blocks), dim3(256), 0, s, js);
+  TG_CHECK_LAUNCH("filter_prep_multi");
   return TG_OK;
 }
 

@@ -35,6 +35,13 @@ class WnJob(C.Structure):
                 ("c_in", C.c_int32), ("c_out", C.c_int32)]
 
 
+class PrepJob(C.Structure):
+    """tg_prep_job: one layer's weight-norm scale + filter re-layout of tg_filter_prep_multi_f32."""
+    _fields_ = [("src", C.c_void_p), ("g", C.c_void_p), ("scale", C.c_void_p), ("dst_same", C.c_void_p), ("dst_tr", C.c_void_p),
+                ("tr_sb", C.c_int64), ("tr_st", C.c_int64), ("t", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("a_pad", C.c_int32),
+                ("b_pad", C.c_int32)]
+
+
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "tg_kernels.h")
 
 _SCALARS = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint32_t": C.c_uint32, "float": C.c_float}

@@ -59,6 +59,21 @@ def _colsum_tile_exists(c_out, seg_rows):
     return len(seg_rows) <= 8 and any(c_out % bn == 0 and all(r >= bm for r in seg_rows) for bm, bn in _IGEMM_TILES)
 
 
+def _run_prep_plan(cx, plan):
+    """tg_filter_prep_multi_f32 for the recorded layers that are not prepared yet; every result goes into the cache tagged with the
+    scratch count its layer would have consumed, so that call-site numbering stays what it was in the recording pass."""
+    todo = [j for j in plan if j['key'] not in cx.prep_cache]
+    for k in range(0, len(todo), 24):
+        part = todo[k:k + 24]
+        arr = (lib.PrepJob * len(part))(*[
+            lib.PrepJob(j['kernel'].data_ptr(), j['g'].data_ptr() if j['g'] is not None else None, j['scale'].data_ptr() if j['g'] is not None else None,
+                        j['w_hwio'].data_ptr(), j['w_oti'].data_ptr(), j['t'] * j['a_pad'], j['a_pad'], j['t'], j['a'], j['b'], j['a_pad'], j['b_pad'])
+            for j in part])
+        lib.call('tg_filter_prep_multi_f32', C.cast(arr, C.c_void_p), len(part), cx.stream)
+    for j in todo:
+        cx.prep_cache[j['key']] = (j['scale'], j['w_oti'], j['w_hwio'], j['bump'], cx.phase)
+
+
 def wgrad_splits(desc, m):
     """pixel splits of tg_wgrad_f32: fill ONE round of the 512 resident workgroups (256 CUs x 2) as fully as possible —
     576 blocks take two rounds and run at 56 % — with at least 128 pixels (4 K-tiles) per split."""
@@ -113,10 +128,20 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     # discriminator once for the G- and C-updates (Context.prep_cache; None outside train_iteration: no caching).
     key = ('conv', kernel.data_ptr(), wn[0].data_ptr() if wn is not None else 0, t, c_in, c_out, ci_p, co_p)
     ent = cx.prep_cache.get(key) if cx.prep_cache is not None else None
+    if ent is None and cx.prep_cache is not None:
+        plan = cx.prep_plans.get((cx.plan_tag, cx.phase, key))
+        if plan is not None:                               # this layer opens a recorded sequence: prepare all of its layers now
+            _run_prep_plan(cx, plan)
+            ent = cx.prep_cache.get(key)
     if ent is not None and (ent[2] is not None or not needs_x):
-        scale, w_oti, w_hwio = ent
+        scale, w_oti, w_hwio = ent[:3]
+        if len(ent) > 3:                                   # produced by a plan in this phase: keep the call-site numbering of the
+            if ent[4] == cx.phase:                         # recording pass, in which this layer allocated its own buffers here
+                cx.counter += ent[3]
+            cx.prep_cache[key] = ent[:3]
     else:
         scale = None
+        c_before = cx.counter
         with cx.on_side(forward=True):                 # weights are final since the phase's fork: runs ahead, beside the previous layer's launch
             # (buffers written on the side stream are also ALLOCATED under it: a first-use zero fill is a launch on the current stream)
             w_oti = cx.scratch('woti', co_p * t * ci_p)
@@ -128,6 +153,9 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
         cx.main_waits_side()
         if cx.prep_cache is not None:
             cx.prep_cache[key] = (scale, w_oti, w_hwio)
+            if cx._prep_rec is not None and w_hwio is not None and not cx.use_side_stream:
+                cx._prep_rec.append(dict(key=key, kernel=kernel, g=wn[0] if wn is not None else None, scale=scale, w_oti=w_oti, w_hwio=w_hwio,
+                                         t=t, a=c_in, b=c_out, a_pad=ci_p, b_pad=co_p, bump=cx.counter - c_before))
     if n_store_ld is None:
         n_store, ld_out = c_out, co_p
     else:

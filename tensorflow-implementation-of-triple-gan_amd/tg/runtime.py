@@ -209,6 +209,12 @@ class Context(object):
         self.side_forward = mode == '1'
         # fp64 statistics accumulators (fused mean-only BN / batch norm) of one solver run live in ONE arena per phase, zeroed by one
         # launch at the start of the phase instead of one memset per layer and direction (36 -> 3 launches per iteration)
+        # forward filter preparation of a whole solver run in two launches: the first pass of a (mode, phase) records the layers that
+        # needed preparing; from then on the layer that opens that sequence launches tg_filter_prep_multi_f32 for all of them
+        self.plan_tag = None           # training mode ('pre' / 'full'), set by Train.train_iteration
+        self.prep_plans = {}           # (plan_tag, phase, first layer key) -> [job dicts]
+        self._planned = set()
+        self._prep_rec = None
         self.tail_jobs = []            # deferred filter-gradient tails of the running backward pass (ops.filter_grad / flush_tails)
         self.prep_cache = None         # {layout key: prepared filter buffers} while Train.train_iteration runs (see ops.conv2d)
         self._zarena = {}              # phase -> dict(sizes=[...], buf=tensor or None, cursor=int, recording=bool)
@@ -377,9 +383,17 @@ class Context(object):
         self._fork_side()
         self._phase_depth += 1
         self._zarena_begin(resume=counter != 0)
+        rec_prev = self._prep_rec
+        tagp = (self.plan_tag, name)
+        self._prep_rec = [] if (self.prep_cache is not None and counter == 0 and tagp not in self._planned) else None
         try:
             yield self
         finally:
+            if self._prep_rec is not None:
+                self._planned.add(tagp)
+                if len(self._prep_rec) >= 2:
+                    self.prep_plans[(self.plan_tag, name, self._prep_rec[0]['key'])] = self._prep_rec
+            self._prep_rec = rec_prev
             self._zarena_end()
             self._phase_depth -= 1
             self._join_side()

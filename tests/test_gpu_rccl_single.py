@@ -43,20 +43,24 @@ if torch.distributed.is_initialized():
 
 def _run(tmp_path, single):
     import torch
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
     out = str(tmp_path / ('single.pt' if single else 'plain.pt'))
     script = tmp_path / ('w%d.py' % single)
     script.write_text(WORKER.format(root=ROOT, out=out))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
-    env.pop('TG_DIST_SINGLE', None)
-    if single:
-        env['TG_DIST_SINGLE'] = '1'
-    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    return torch.load(out, weights_only=False)
+    err = ''
+    for attempt in range(2):              # one retry with a fresh rendezvous port: the process-group start-up is outside what is tested
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+        env.pop('TG_DIST_SINGLE', None)
+        if single:
+            env['TG_DIST_SINGLE'] = '1'
+        r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode == 0:
+            return torch.load(out, weights_only=False)
+        err = r.stderr[-3000:]
+    raise AssertionError(err)
 
 
 def test_one_replica_rccl_run_is_bit_identical(tmp_path):
