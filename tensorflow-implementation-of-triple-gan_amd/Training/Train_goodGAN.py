@@ -235,6 +235,8 @@ class Train(Train_base):
         if self._graphs is None:
             self._graphs = {}
         graphs = self._graphs.setdefault(key, [None] * len(segs))
+        if use_graph and key in self._warm_keys and any(g is None for g in graphs):
+            self._capture(segs, graphs, key)
         pending = []
         cx.prep_cache = {}                              # filter layouts stay valid between a network's optimiser steps
         cx.plan_tag = key
@@ -244,16 +246,7 @@ class Train(Train_base):
                     for wk in pending:
                         tgdist.wait_(wk)
                     pending = []
-                if use_graph and key in self._warm_keys:
-                    if graphs[i] is None:
-                        import ctypes as C
-                        lib.call('tg_graph_begin_capture', cx.stream)
-                        try:
-                            fn()
-                        finally:
-                            h = C.c_void_p()
-                            lib.call('tg_graph_end_capture', cx.stream, C.byref(h))
-                        graphs[i] = h
+                if use_graph and graphs[i] is not None:
                     lib.call('tg_graph_launch', graphs[i], cx.stream)
                 else:
                     fn()
@@ -267,6 +260,34 @@ class Train(Train_base):
         self._warm = True
         self._warm_keys.add(key)       # graphs of a mode are captured from its SECOND iteration on: the first one allocates its buffers eagerly
         self.iteration += 1
+
+    def _capture(self, segs, graphs, key):
+        """Record every segment of one iteration as a hipGraph — all of them back to back, nothing launched and no collective issued
+        in between.  With replicas the process group must be QUIET while a stream captures: on ROCm the RCCL watchdog thread's
+        hipEventQuery on a pending collective fails with hipErrorCapturedEvent during another thread's capture (even in thread-local
+        capture mode) and takes the process down, so the device is drained and the watchdog given time to retire its work list."""
+        import ctypes as C
+        cx = self.cx
+        if tgdist.active():
+            torch.cuda.synchronize()
+            time.sleep(1.0)                              # several of the watchdog's 100 ms sweeps
+        cx.prep_cache = {}
+        cx.plan_tag = key
+        try:
+            for i, (fn, _grads, _overlap) in enumerate(segs):
+                if graphs[i] is not None:
+                    continue
+                lib.call('tg_graph_begin_capture', cx.stream)
+                try:
+                    if os.environ.get('TG_DEBUG_CAPTURE_SLEEP'):          # test hook: widen the capture window
+                        time.sleep(float(os.environ['TG_DEBUG_CAPTURE_SLEEP']))
+                    fn()
+                finally:
+                    h = C.c_void_p()
+                    lib.call('tg_graph_end_capture', cx.stream, C.byref(h))
+                graphs[i] = h
+        finally:
+            cx.prep_cache = None
 
     def losses(self):
         """(d_loss, g_loss, c_loss) of the last iteration — a device->host sync; call sparingly."""

@@ -1,7 +1,8 @@
 """RCCL code path on the one-GPU dev box: TG_DIST_SINGLE=1 creates a ONE-replica nccl process group and routes every collective of
 the trainer through it (communicator bound to the device, weight broadcast, bucketed gradient exchange with the asynchronous
 all-reduce beside a hipGraph launch, barrier, max-over-ranks).  A one-rank sum is the identity, so the run must be bit-identical
-to the plain single-process run.  (Several ranks cannot share one GPU under RCCL; tests/test_gpu_dp.py covers two ranks with
+to the plain single-process run.  The run also widens the hipGraph capture windows to check that no collective is pending on the RCCL
+watchdog while a stream captures (see Train._capture).  (Several ranks cannot share one GPU under RCCL; tests/test_gpu_dp.py covers two ranks with
 gloo as the transport.)"""
 import os
 import socket
@@ -56,10 +57,16 @@ def _run(tmp_path, single):
         env.pop('TG_DIST_SINGLE', None)
         if single:
             env['TG_DIST_SINGLE'] = '1'
+            # widen every capture window beyond the RCCL watchdog's polling period: a collective still on the watchdog's list while a
+            # stream captures kills the process on ROCm (hipErrorCapturedEvent) — Train._capture must have drained the list before
+            env['TG_DEBUG_CAPTURE_SLEEP'] = '0.3'
         r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
         if r.returncode == 0:
             return torch.load(out, weights_only=False)
         err = r.stderr[-3000:]
+    dbg = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(dbg):
+        open(os.path.join(dbg, 'rccl_single_stderr.txt'), 'w').write(err)
     raise AssertionError(err)
 
 
