@@ -339,6 +339,16 @@ int tg_rng_keep_mask_f32(float* out, int64_t n, float keep_prob, const uint64_t*
 int tg_rng_normal_f32(float* out, int64_t n, float stddev, const uint64_t* state, uint32_t stream_id, void* stream);
 int tg_rng_onehot_f32(float* out, int rows, int k, const uint64_t* state, uint32_t stream_id, void* stream);
 int tg_rng_advance(uint64_t* state, void* stream);
+/* Up to 16 of the draws above in ONE launch (all random inputs of a solver run): mode 0 uniform [a,b), 1 keep-mask with probability a,
+ * 2 normal(0,a), 3 one-hot of a classes per row (n = rows).  Bit-identical to the single calls (same counters). */
+typedef struct tg_rng_job {
+  float* out;
+  int64_t n;
+  int32_t mode;
+  float a, b;
+  uint32_t stream_id;
+} tg_rng_job;
+int tg_rng_multi_f32(const tg_rng_job* jobs, int n_jobs, const uint64_t* state, void* stream);
 
 #ifdef __cplusplus
 }

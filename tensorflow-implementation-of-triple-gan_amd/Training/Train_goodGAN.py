@@ -222,8 +222,11 @@ class Train(Train_base):
         """z ~ U(-1,1), y ~ onehot(U{0..9}) (:234-239) drawn on the device."""
         cx = self.cx
         with cx.rng_scoped('latent'):
-            cx.rng.uniform(cx, 'z', self.z_g_ph.t.numel(), -1.0, 1.0, out=self.z_g_ph.t)
-            cx.rng.onehot(cx, 'y', self.y_g_ph.n, self.config.NUM_CLASSES, out=self.y_g_ph.t)
+            if hasattr(cx.rng, 'latents'):
+                cx.rng.latents(cx, self.z_g_ph.t, self.y_g_ph.t, self.y_g_ph.n, self.config.NUM_CLASSES)
+            else:
+                cx.rng.uniform(cx, 'z', self.z_g_ph.t.numel(), -1.0, 1.0, out=self.z_g_ph.t)
+                cx.rng.onehot(cx, 'y', self.y_g_ph.n, self.config.NUM_CLASSES, out=self.y_g_ph.t)
 
     def train_iteration(self, pre_train=False, use_graph=None):
         """D-update, G-update, C-update on the current placeholder contents (:266-276).  No host sync."""

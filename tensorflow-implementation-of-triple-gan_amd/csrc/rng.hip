@@ -56,6 +56,44 @@ __global__ void rng_onehot_kernel(float* __restrict__ out, int rows, int k, cons
   for (int j = 0; j < k; ++j) out[r * k + j] = j == cls ? 1.f : 0.f;
 }
 
+constexpr int MAX_RNG_JOBS = 16;
+struct RngJobs { tg_rng_job j[MAX_RNG_JOBS]; };
+
+// blockIdx.y = job; per job exactly the arithmetic of rng_kernel / rng_onehot_kernel
+__global__ void __launch_bounds__(256) rng_multi_kernel(RngJobs js, const uint64_t* __restrict__ state) {
+  const tg_rng_job& J = js.j[blockIdx.y];
+  const uint64_t seed = state[0], step = state[1];
+  if (J.mode == 3) {
+    const int k = (int)J.a;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < J.n; r += (int64_t)gridDim.x * blockDim.x) {
+      const u4 q = philox((uint32_t)r, 0u, J.stream_id, (uint32_t)step, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32));
+      const int cls = (int)(((uint64_t)q.x * (uint64_t)k) >> 32);
+      for (int c = 0; c < k; ++c) J.out[r * k + c] = c == cls ? 1.f : 0.f;
+    }
+    return;
+  }
+  const int64_t n4 = (J.n + 3) / 4;
+  const float a = J.a, b = J.b;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const u4 r = philox((uint32_t)i, (uint32_t)(i >> 32), J.stream_id, (uint32_t)step, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32));
+    float v[4];
+    if (J.mode == 2) {
+      const float r0 = sqrtf(-2.f * logf(u01(r.x))), r1 = sqrtf(-2.f * logf(u01(r.z)));
+      float s0, c0, s1, c1;
+      sincosf(6.283185307179586f * u01(r.y), &s0, &c0);
+      sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
+      v[0] = a * r0 * c0; v[1] = a * r0 * s0; v[2] = a * r1 * c1; v[3] = a * r1 * s1;
+    } else {
+      const float u[4] = {u01(r.x), u01(r.y), u01(r.z), u01(r.w)};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = J.mode == 0 ? a + (b - a) * u[k] : (u[k] < a ? 1.f : 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i * 4 + k < J.n) J.out[i * 4 + k] = v[k];
+  }
+}
+
 __global__ void rng_advance_kernel(uint64_t* state) { if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += 1; }
 
 int ew_grid(int64_t work) {
@@ -92,6 +130,25 @@ int tg_rng_onehot_f32(float* out, int rows, int k, const uint64_t* state, uint32
   TG_CHECK_LAUNCH("rng_onehot_kernel");
   return TG_OK;
 }
+int tg_rng_multi_f32(const tg_rng_job* jobs, int n_jobs, const uint64_t* state, void* stream) {
+  TG_REQUIRE(jobs && state && n_jobs >= 1 && n_jobs <= MAX_RNG_JOBS, "rng_multi: n_jobs=%d out of range", n_jobs);
+  RngJobs js;
+  int64_t mx = 0;
+  double bytes = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    TG_REQUIRE(jobs[i].out && jobs[i].n > 0 && jobs[i].mode >= 0 && jobs[i].mode <= 3, "rng_multi: job %d bad", i);
+    js.j[i] = jobs[i];
+    const int64_t work = jobs[i].mode == 3 ? jobs[i].n : (jobs[i].n + 3) / 4;
+    mx = work > mx ? work : mx;
+    bytes += 4.0 * jobs[i].n * (jobs[i].mode == 3 ? jobs[i].a : 1.f);
+  }
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_ELEMWISE, 0, bytes, s);
+  hipLaunchKernelGGL(rng_multi_kernel, dim3(ew_grid(mx), n_jobs), dim3(256), 0, s, js, state);
+  TG_CHECK_LAUNCH("rng_multi_kernel");
+  return TG_OK;
+}
+
 int tg_rng_advance(uint64_t* state, void* stream) {
   TG_REQUIRE(state, "rng_advance: null state");
   hipStream_t s = tg::as_stream(stream);

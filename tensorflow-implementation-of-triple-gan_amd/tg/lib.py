@@ -42,6 +42,11 @@ class PrepJob(C.Structure):
                 ("b_pad", C.c_int32)]
 
 
+class RngJob(C.Structure):
+    """tg_rng_job: one random draw of tg_rng_multi_f32."""
+    _fields_ = [("out", C.c_void_p), ("n", C.c_int64), ("mode", C.c_int32), ("a", C.c_float), ("b", C.c_float), ("stream_id", C.c_uint32)]
+
+
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "tg_kernels.h")
 
 _SCALARS = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint32_t": C.c_uint32, "float": C.c_float}
@@ -63,6 +68,8 @@ def _ctype_of(decl):
             return C.POINTER(C.c_void_p)
         if name in HOST_INT_ARRAYS:
             return C.POINTER(C.c_int32)
+        if name == "state":
+            return C.c_void_p
         if name in ("ms", "flops", "bytes"):
             return C.POINTER(C.c_double)
         if name == "launches":

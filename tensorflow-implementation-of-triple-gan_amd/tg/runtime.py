@@ -151,11 +151,17 @@ class InjectedRNG(object):
 
 
 class PhiloxRNG(object):
-    """Production RNG: tg_rng_* kernels; (seed, step) in device memory so hipGraph replays draw fresh numbers."""
+    """Production RNG: tg_rng_* kernels; (seed, step) in device memory so hipGraph replays draw fresh numbers.
+    Inside Train.train_iteration the draws of a solver run are recorded the first time (buffer, size, distribution, stream id) and
+    from then on generated by ONE tg_rng_multi_f32 launch at the first request of the run — the values are the same (counter-based
+    generator: every draw is a function of (seed, step, stream id, element index) only)."""
 
     def __init__(self, seed, device):
         self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
         self.stream_ids = {}
+        self.plans = {}                  # (plan_tag, phase) -> [(out tensor, n, mode, a, b, sid)]
+        self._plan = self._rec = None
+        self._cursor = 0
 
     def _sid(self, ctx, name):
         key = ctx.rng_scope + '/' + name
@@ -163,25 +169,57 @@ class PhiloxRNG(object):
             self.stream_ids[key] = len(self.stream_ids) + 1
         return self.stream_ids[key]
 
-    def keep_mask(self, ctx, name, n, keep):
-        out = ctx.ws('rng:' + ctx.rng_scope + '/' + name, n)
-        lib.call('tg_rng_keep_mask_f32', lib.ptr(out), n, keep, lib.ptr(self.state), self._sid(ctx, name), ctx.stream)
+    # ---- per solver run -------------------------------------------------------------------------
+    def begin_phase(self, ctx):
+        key = (ctx.plan_tag, ctx.phase)
+        on = ctx.prep_cache is not None and os.environ.get('TG_RNG_MULTI', '1') != '0'   # only inside Train.train_iteration
+        self._plan = self.plans.get(key) if on else None
+        self._rec = [] if (on and self._plan is None) else None
+        self._cursor = 0
+
+    def end_phase(self, ctx):
+        if self._rec is not None and len(self._rec) >= 2:
+            self.plans[(ctx.plan_tag, ctx.phase)] = self._rec
+        self._plan = self._rec = None
+
+    def _multi(self, ctx, jobs):
+        arr = (lib.RngJob * len(jobs))(*[lib.RngJob(j[0].data_ptr(), j[1], j[2], j[3], j[4], j[5]) for j in jobs])
+        lib.call('tg_rng_multi_f32', C.cast(arr, C.c_void_p), len(jobs), lib.ptr(self.state), ctx.stream)
+
+    def _draw(self, ctx, name, n, mode, a, b, out=None):
+        if out is None:
+            out = ctx.ws('rng:' + ctx.rng_scope + '/' + name, n * (int(a) if mode == 3 else 1))
+        sid = self._sid(ctx, name)
+        job = (out, int(n), mode, float(a), float(b), sid)
+        if self._plan is not None and self._cursor < len(self._plan):
+            want = self._plan[self._cursor]
+            if want[0].data_ptr() == out.data_ptr() and want[1:] == job[1:]:
+                if self._cursor == 0:
+                    for k in range(0, len(self._plan), 16):
+                        self._multi(ctx, self._plan[k:k + 16])
+                self._cursor += 1
+                return out
+            self._plan = None                              # a different sequence than recorded: single launches (same values)
+        self._multi(ctx, [job])
+        if self._rec is not None:
+            self._rec.append(job)
         return out
+
+    def keep_mask(self, ctx, name, n, keep):
+        return self._draw(ctx, name, n, 1, keep, 0.0)
 
     def normal(self, ctx, name, n, std):
-        out = ctx.ws('rng:' + ctx.rng_scope + '/' + name, n)
-        lib.call('tg_rng_normal_f32', lib.ptr(out), n, std, lib.ptr(self.state), self._sid(ctx, name), ctx.stream)
-        return out
+        return self._draw(ctx, name, n, 2, std, 0.0)
 
     def uniform(self, ctx, name, n, lo, hi, out=None):
-        out = ctx.ws('rng:' + ctx.rng_scope + '/' + name, n) if out is None else out
-        lib.call('tg_rng_uniform_f32', lib.ptr(out), n, lo, hi, lib.ptr(self.state), self._sid(ctx, name), ctx.stream)
-        return out
+        return self._draw(ctx, name, n, 0, lo, hi, out)
 
     def onehot(self, ctx, name, rows, k, out=None):
-        out = ctx.ws('rng:' + ctx.rng_scope + '/' + name, rows * k) if out is None else out
-        lib.call('tg_rng_onehot_f32', lib.ptr(out), rows, k, lib.ptr(self.state), self._sid(ctx, name), ctx.stream)
-        return out
+        return self._draw(ctx, name, rows, 3, k, 0.0, out)
+
+    def latents(self, ctx, z_out, y_out, rows, k, lo=-1.0, hi=1.0):
+        """z ~ U(lo,hi) and y ~ onehot(U{0..k-1}) (Training/Train_goodGAN.py:234-239) in one launch."""
+        self._multi(ctx, [(z_out, z_out.numel(), 0, float(lo), float(hi), self._sid(ctx, 'z')), (y_out, int(rows), 3, float(k), 0.0, self._sid(ctx, 'y'))])
 
     def advance(self, ctx):
         lib.call('tg_rng_advance', lib.ptr(self.state), ctx.stream)
@@ -383,6 +421,8 @@ class Context(object):
         self._fork_side()
         self._phase_depth += 1
         self._zarena_begin(resume=counter != 0)
+        if counter == 0 and hasattr(self.rng, 'begin_phase'):
+            self.rng.begin_phase(self)
         rec_prev = self._prep_rec
         tagp = (self.plan_tag, name)
         self._prep_rec = [] if (self.prep_cache is not None and counter == 0 and tagp not in self._planned) else None
@@ -394,6 +434,8 @@ class Context(object):
                 if len(self._prep_rec) >= 2:
                     self.prep_plans[(self.plan_tag, name, self._prep_rec[0]['key'])] = self._prep_rec
             self._prep_rec = rec_prev
+            if hasattr(self.rng, 'end_phase') and counter == 0:
+                self.rng.end_phase(self)
             self._zarena_end()
             self._phase_depth -= 1
             self._join_side()
