@@ -271,7 +271,7 @@ class Train(Train_base):
         capture mode) and takes the process down, so the device is drained and the watchdog given time to retire its work list."""
         import ctypes as C
         cx = self.cx
-        if tgdist.active():
+        if tgdist.quiet_capture_needed():
             torch.cuda.synchronize()
             time.sleep(1.0)                              # several of the watchdog's 100 ms sweeps
         cx.prep_cache = {}

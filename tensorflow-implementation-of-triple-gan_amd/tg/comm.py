@@ -1,0 +1,126 @@
+"""ctypes binding of include/tg_comm.h (libtg_comm.so): RCCL collectives called directly on the launch stream — no process group,
+no watchdog thread, legal inside hipStream capture.  Selected by TG_DIST_BACKEND=rccl-direct (tg/dist.py); the communicator id
+travels from rank 0 to the other ranks through a torch.distributed.TCPStore at MASTER_ADDR:MASTER_PORT (rendezvous only).
+
+libtg_comm.so is built WITHOUT a link to librccl so that the process holds exactly one RCCL: the copy PyTorch ships (already
+mapped once `import torch` has run on a ROCm build) is promoted to the global symbol scope here, /opt/rocm's otherwise."""
+import ctypes as C
+import os
+
+from . import lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libtg_comm.so")
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "tg_comm.h")
+ID_BYTES = 128
+
+_lib = None
+
+
+def _rccl_candidates():
+    try:
+        import torch
+        yield os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    except ImportError:
+        pass
+    yield "/opt/rocm/lib/librccl.so.1"
+    yield "librccl.so.1"
+
+
+def load():
+    """dlopen RCCL (RTLD_GLOBAL) then libtg_comm.so; raises TgError when either is missing — there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise lib.TgError("%s not built: run `make -C %s` (or __graft_entry__.build())" % (LIB_PATH, os.path.dirname(LIB_PATH)))
+    err = None
+    for cand in _rccl_candidates():
+        if os.path.isabs(cand) and not os.path.exists(cand):
+            continue
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            err = None
+            break
+        except OSError as e:
+            err = e
+    if err is not None:
+        raise lib.TgError("no RCCL library could be loaded: %s" % err)
+    l = C.CDLL(LIB_PATH)
+    vp, i64, ci = C.c_void_p, C.c_int64, C.c_int
+    l.tg_comm_last_error_string.restype = C.c_char_p
+    l.tg_comm_last_error_string.argtypes = []
+    sigs = {
+        'tg_comm_unique_id': [vp],
+        'tg_comm_init_rank': [C.POINTER(vp), ci, vp, ci, ci],
+        'tg_comm_count': [vp, C.POINTER(ci), C.POINTER(ci)],
+        'tg_allreduce_sum_f32': [vp, i64, vp, vp],
+        'tg_allreduce_max_f64': [vp, i64, vp, vp],
+        'tg_broadcast_f32': [vp, i64, ci, vp, vp],
+        'tg_comm_destroy': [vp],
+    }
+    for name, argt in sigs.items():
+        f = getattr(l, name)
+        f.argtypes = argt
+        f.restype = ci
+    _lib = l
+    return l
+
+
+def call(name, *args):
+    l = load()
+    rc = getattr(l, name)(*args)
+    if rc != 0:
+        raise lib.TgError("%s failed (%d): %s" % (name, rc, l.tg_comm_last_error_string().decode()))
+
+
+class Communicator(object):
+    """one RCCL communicator of `world` ranks bound to HIP device `device`."""
+
+    def __init__(self, world, rank, device, unique_id):
+        assert len(unique_id) == ID_BYTES
+        self.world, self.rank, self.device = world, rank, device
+        self.handle = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), ID_BYTES)
+        call('tg_comm_init_rank', C.byref(self.handle), world, C.cast(buf, C.c_void_p), rank, device)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(ID_BYTES)
+        call('tg_comm_unique_id', C.cast(buf, C.c_void_p))
+        return buf.raw
+
+    def allreduce_sum_(self, t, stream=None):
+        assert t.dtype.is_floating_point and t.element_size() == 4 and t.is_contiguous()
+        call('tg_allreduce_sum_f32', lib.ptr(t), t.numel(), self.handle, lib.cur_stream() if stream is None else stream)
+        return t
+
+    def allreduce_max_f64_(self, t, stream=None):
+        assert t.element_size() == 8 and t.is_contiguous()
+        call('tg_allreduce_max_f64', lib.ptr(t), t.numel(), self.handle, lib.cur_stream() if stream is None else stream)
+        return t
+
+    def broadcast_(self, t, root=0, stream=None):
+        assert t.element_size() == 4 and t.is_contiguous()
+        call('tg_broadcast_f32', lib.ptr(t), t.numel(), root, self.handle, lib.cur_stream() if stream is None else stream)
+        return t
+
+    def destroy(self):
+        if self.handle:
+            call('tg_comm_destroy', self.handle)
+            self.handle = C.c_void_p()
+
+
+def rendezvous(world, rank, device):
+    """rank 0 draws the communicator id and publishes it in a TCPStore at MASTER_ADDR:MASTER_PORT; every rank joins."""
+    import datetime
+    import torch.distributed as dist
+    addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = int(os.environ.get('MASTER_PORT', '29500'))
+    if world == 1:
+        return Communicator(1, 0, device, Communicator.unique_id()), None
+    store = dist.TCPStore(addr, port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=300))
+    if rank == 0:
+        store.set('tg_comm_id', Communicator.unique_id())
+    uid = store.get('tg_comm_id')
+    return Communicator(world, rank, device, uid), store

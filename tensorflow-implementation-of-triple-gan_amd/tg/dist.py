@@ -13,6 +13,10 @@ import torch.distributed as dist
 # one-GPU box; results are unchanged (a one-rank sum is the identity).
 SINGLE = os.environ.get('TG_DIST_SINGLE') == '1'
 
+# TG_DIST_BACKEND=rccl-direct: no torch process group — the collectives are tg_comm.h calls (libtg_comm.so) on the launch stream.
+_direct = None            # tg.comm.Communicator
+_direct_store = None      # keeps the rendezvous TCPStore alive
+
 
 def env_world():
     return int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
@@ -20,12 +24,18 @@ def env_world():
 
 def init(backend=None):
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  Returns (world, rank, local_rank)."""
+    global _direct, _direct_store
     world, rank, local = env_world()
-    if (world > 1 or SINGLE) and not dist.is_initialized():
+    if (world > 1 or SINGLE) and not dist.is_initialized() and _direct is None:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
             backend = os.environ.get('TG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if backend == 'rccl-direct':
+            from . import comm
+            torch.cuda.set_device(local)
+            _direct, _direct_store = comm.rendezvous(world, rank, local)
+            return world, rank, local
         if 'TG_DEVICE_INDEX' in os.environ:        # rehearsal of N ranks on one GPU (gloo): every rank uses this device
             local = int(os.environ['TG_DEVICE_INDEX'])
         if torch.cuda.is_available():
@@ -40,21 +50,35 @@ def init(backend=None):
 
 
 def world_size():
+    if _direct is not None:
+        return _direct.world
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
 def active():
     """collectives are issued: more than one replica (or the one-replica RCCL rehearsal)."""
+    if _direct is not None:
+        return _direct.world > 1 or SINGLE
     return dist.is_initialized() and (dist.get_world_size() > 1 or SINGLE)
 
 
+def quiet_capture_needed():
+    """a process group's watchdog thread polls events of pending collectives — it must be idle while a stream captures
+    (Training/Train_goodGAN.py:_capture).  The direct backend has no such thread."""
+    return active() and _direct is None
+
+
 def rank():
+    if _direct is not None:
+        return _direct.rank
     return dist.get_rank() if dist.is_initialized() else 0
 
 
 def allreduce_sum_(flat):
     """in-place sum over replicas of a flat gradient buffer (one collective per network per iteration)."""
     if active():
+        if _direct is not None:
+            return _direct.allreduce_sum_(flat)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
@@ -63,6 +87,9 @@ def allreduce_sum_async_(flat):
     """Start the in-place sum on RCCL's own stream — it waits for what the current stream has enqueued so far and runs beside
     whatever is enqueued next (the remaining backward pass).  Returns a handle for wait_(); None on one replica."""
     if active():
+        if _direct is not None:                     # stream-ordered on the launch stream: nothing to wait for
+            _direct.allreduce_sum_(flat)
+            return None
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
     return None
 
@@ -75,13 +102,15 @@ def wait_(work):
 
 def allreduce_mean_(flat):
     if active():
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        allreduce_sum_(flat)
         flat.div_(world_size())
     return flat
 
 
 def broadcast_(flat, src=0):
     if active():
+        if _direct is not None:
+            return _direct.broadcast_(flat, src)
         dist.broadcast(flat, src=src)
     return flat
 
@@ -89,10 +118,27 @@ def broadcast_(flat, src=0):
 def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if active():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if _direct is not None:
+            _direct.allreduce_max_f64_(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def barrier():
     if active():
-        dist.barrier()
+        if _direct is not None:                      # a one-element sum every rank must reach, then drain the stream
+            _direct.allreduce_sum_(torch.zeros(1, dtype=torch.float32, device='cuda'))
+            torch.cuda.synchronize()
+        else:
+            dist.barrier()
+
+
+def shutdown():
+    global _direct, _direct_store
+    if _direct is not None:
+        torch.cuda.synchronize()
+        _direct.destroy()
+        _direct = _direct_store = None
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -95,3 +95,17 @@ def test_product_never_imports_the_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 assert not pat.search(open(os.path.join(dirpath, f)).read()), os.path.join(dirpath, f)
+
+
+def test_comm_library_exports_every_declared_symbol():
+    """include/tg_comm.h <-> libtg_comm.so (no collective is issued: loading needs RCCL in the process, not a GPU)."""
+    from tg import comm, lib
+    header = os.path.join(ROOT, "include", "tg_comm.h")
+    subprocess.check_call(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", header])
+    names = _declared(header)
+    assert len(names) == 8
+    handle = comm.load()
+    for n in sorted(names):
+        assert hasattr(handle, n), n
+    with pytest.raises(lib.TgError, match="null"):
+        comm.call('tg_comm_count', None, None, None)

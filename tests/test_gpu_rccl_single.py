@@ -34,18 +34,18 @@ tr.sync_running_state()
 tgdist.barrier()
 t = tgdist.max_over_ranks(1.25, tr.cx.device)
 torch.cuda.synchronize()
-out = dict(active=tgdist.active(), backend=(torch.distributed.get_backend() if torch.distributed.is_initialized() else None), t=t,
+backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else ('rccl-direct' if tgdist._direct is not None else None)
+out = dict(active=tgdist.active(), backend=backend, t=t,
            losses=tr.losses(), p={{k: st.p.cpu().numpy() for k, st in tr.cx.stores.items()}})
 torch.save(out, {out!r})
-if torch.distributed.is_initialized():
-    torch.distributed.destroy_process_group()
+tgdist.shutdown()
 '''
 
 
-def _run(tmp_path, single):
+def _run(tmp_path, single, backend=None):
     import torch
-    out = str(tmp_path / ('single.pt' if single else 'plain.pt'))
-    script = tmp_path / ('w%d.py' % single)
+    out = str(tmp_path / ('single%s.pt' % (backend or '') if single else 'plain.pt'))
+    script = tmp_path / ('w%d%s.py' % (single, backend or ''))
     script.write_text(WORKER.format(root=ROOT, out=out))
     err = ''
     for attempt in range(2):              # one retry with a fresh rendezvous port: the process-group start-up is outside what is tested
@@ -55,6 +55,9 @@ def _run(tmp_path, single):
         s.close()
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
         env.pop('TG_DIST_SINGLE', None)
+        env.pop('TG_DIST_BACKEND', None)
+        if backend:
+            env['TG_DIST_BACKEND'] = backend
         if single:
             env['TG_DIST_SINGLE'] = '1'
             # widen every capture window beyond the RCCL watchdog's polling period: a collective still on the watchdog's list while a
@@ -78,3 +81,52 @@ def test_one_replica_rccl_run_is_bit_identical(tmp_path):
     assert single['losses'] == plain['losses']
     for k in plain['p']:
         np.testing.assert_array_equal(single['p'][k], plain['p'][k], err_msg=k)
+
+
+def test_one_replica_direct_rccl_run_is_bit_identical(tmp_path):
+    """the same run with TG_DIST_BACKEND=rccl-direct: every collective is a tg_comm.h call (libtg_comm.so) on the launch stream."""
+    plain = _run(tmp_path, False)
+    single = _run(tmp_path, True, backend='rccl-direct')
+    assert single['active'] is True and single['backend'] == 'rccl-direct'
+    assert single['t'] == 1.25
+    assert single['losses'] == plain['losses']
+    for k in plain['p']:
+        np.testing.assert_array_equal(single['p'][k], plain['p'][k], err_msg=k)
+
+
+def test_comm_entry_points_one_rank():
+    """tg_comm.h through the C ABI on a one-rank communicator: sum / max / broadcast are identities, also when recorded into a
+    hipGraph and replayed; argument errors come back as status codes with a message."""
+    import ctypes as C
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tensorflow-implementation-of-triple-gan_amd"))
+    from tg import comm, lib
+    c = comm.Communicator(1, 0, 0, comm.Communicator.unique_id())
+    n, r = C.c_int(), C.c_int()
+    comm.call('tg_comm_count', c.handle, C.byref(n), C.byref(r))
+    assert (n.value, r.value) == (1, 0)
+    x = torch.randn(1 << 20, device='cuda')
+    ref = x.clone()
+    c.allreduce_sum_(x)
+    c.broadcast_(x, 0)
+    d = torch.tensor([3.5, -1.0], dtype=torch.float64, device='cuda')
+    c.allreduce_max_f64_(d)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref) and d.tolist() == [3.5, -1.0]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        lib.call('tg_graph_begin_capture', s.cuda_stream)
+        c.allreduce_sum_(x, stream=s.cuda_stream)
+        x.mul_(2.0)
+        h = C.c_void_p()
+        lib.call('tg_graph_end_capture', s.cuda_stream, C.byref(h))
+        for _ in range(3):
+            lib.call('tg_graph_launch', h, s.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref * 8.0)
+    lib.call('tg_graph_destroy', h)
+    with pytest.raises(lib.TgError, match='root'):
+        comm.call('tg_broadcast_f32', lib.ptr(x), 4, 3, c.handle, None)
+    with pytest.raises(lib.TgError, match='count'):
+        comm.call('tg_allreduce_sum_f32', lib.ptr(x), -1, c.handle, None)
+    c.destroy()
