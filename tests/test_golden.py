@@ -1,5 +1,5 @@
 """Golden vectors of SURVEY §8c (tests/golden/cifar10_small_k10.npz, written by tests/golden/make_golden.py from the float64
-restatement): the oracle must keep reproducing them (guards the checker against accidental edits)."""
+restatement; goodgan_{mnist,svhn}_k5.npz by make_golden_goodgan.py): the oracle must keep reproducing them (guards the checker against accidental edits)."""
 import os
 import sys
 
@@ -22,3 +22,16 @@ def test_oracle_reproduces_the_golden_prefix():
     np.testing.assert_allclose(out['logits_init'], g['logits_init'], rtol=1e-9, atol=1e-12)
     assert out['acc_init'] == float(g['acc_init'])
     assert g['losses'].shape == (10, 3) and g['sample_final'].shape == (8, 32, 32, 3) and g['logits_final'].shape == (M.N_TEST, 10)
+
+
+def test_goodgan_oracle_reproduces_the_golden_prefix():
+    import make_golden_goodgan as M
+    for data in M.DATASETS:
+        g = np.load(M.path(data))
+        out = M.run(data, k_steps=1)                         # one of the five iterations keeps the CPU suite short
+        np.testing.assert_allclose(out['losses'], g['losses'][:1], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(out['sample_init'], g['sample_init'], rtol=0, atol=1e-6)    # stored as float32
+        np.testing.assert_allclose(out['logits_init'], g['logits_init'], rtol=1e-9, atol=1e-12)
+        assert out['acc_init'] == float(g['acc_init'])
+        assert g['losses'].shape == (M.K, 3) and g['logits_final'].shape == (M.N_TEST, 10)
+        assert g['sample_final'].shape[0] == M.N_SAMPLE and np.isfinite(g['losses']).all()

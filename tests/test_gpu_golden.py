@@ -57,3 +57,57 @@ def test_hip_path_matches_the_golden_vectors():
         assert abs(p.sum() - s1) <= 4 * lr * M.K * np.sqrt(p.size) and abs((p * p).sum() - s2) <= 2e-3 * s2, net
     assert np.abs(tr.sample(z, y) - g['sample_final']).mean() <= 0.05
     assert abs(evaluate() - float(g['acc_final'])) <= 0.1
+
+
+@pytest.mark.parametrize("data", ['mnist', 'svhn'])
+def test_goodgan_hip_path_matches_the_golden_vectors(data):
+    """Model/Good_GAN.py against tests/golden/goodgan_<data>_k5.npz."""
+    import torch
+    import make_golden_goodgan as M
+    from Model.Good_GAN import Good_GAN
+    from tg.runtime import InjectedRNG
+    g = np.load(M.path(data))
+    tr = G.fresh_trainer(G.make_config_goodgan(data, M.SIZES), M.init_params(data), Good_GAN)
+    h = M.HYPER[data]
+    tr.set_hyper(h['lr'], h['cla_lr'], h['lambda_1'], h['lambda_2'])
+    cx, m = tr.cx, tr.model
+    z, y = M.sample_latents()
+    xt, yt, rnd = M.test_split(data)
+
+    def evaluate():
+        cx.rng = InjectedRNG({'val/C/' + k: v for k, v in rnd.items()}, cx.device)
+        with cx.phase_scope('val', record=False):
+            with cx.rng_scoped('val/C'):
+                logits, _ = m.classifier(cx.from_numpy(xt), False)
+        cx.rng = InjectedRNG({'val/C/' + k: v for k, v in rnd.items()}, cx.device)
+        return logits.numpy(), tr.evaluate([(xt, yt)])
+
+    def sample():
+        return tr.sample(z, y).reshape(g['sample_init'].shape)
+
+    # initial weights: deterministic functions of the inputs -> fp32 tolerance
+    assert G.rel_err(sample(), g['sample_init']) < 2e-4
+    logits, acc = evaluate()
+    assert G.rel_err(logits, g['logits_init']) < 2e-4
+    assert abs(acc - float(g['acc_init'])) <= 1.0 / M.N_TEST + 1e-9
+    losses = []
+    for k in range(M.K):
+        b, r = M.inputs(data, k)
+        cx.rng = InjectedRNG(G.injected_arrays_goodgan(r), cx.device)
+        tr.feed(b)
+        tr.train_iteration(use_graph=False)
+        losses.append(tr.losses())
+    torch.cuda.synchronize()
+    losses, ref = np.asarray(losses), g['losses']
+    assert np.abs(losses[0] - ref[0]).max() <= 5e-4 * max(1.0, np.abs(ref[0]).max())      # first iteration: identical weights
+    assert np.abs(losses - ref).max() <= 0.15, np.abs(losses - ref).max(axis=1)           # then free-running (see the CIFAR-10 test)
+    for net in ('good_generator', 'discriminator', 'classifier'):
+        st = cx.stores[net]
+        p = np.concatenate([st.get(k).reshape(-1).astype(np.float64) for k in st.names(True)])
+        s1, s2 = g['checksum/' + net]
+        lr = h['cla_lr'] if net == 'classifier' else h['lr']
+        assert abs(p.sum() - s1) <= 4 * lr * M.K * np.sqrt(p.size) and abs((p * p).sum() - s2) <= 2e-3 * s2, net
+    assert np.abs(sample() - g['sample_final']).mean() <= 0.05
+    logits, acc = evaluate()
+    assert np.abs(logits - g['logits_final']).mean() <= 0.1 * max(1.0, np.abs(g['logits_final']).mean())
+    assert abs(acc - float(g['acc_final'])) <= 0.1
