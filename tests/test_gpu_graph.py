@@ -9,8 +9,10 @@ import gpu_common as G
 pytestmark = pytest.mark.gpu
 
 
-def run(use_graph, steps=4):
-    sizes = dict(B_G=16, L_C=8, U_C=8, L_D=4, U_D=12)
+SMALL = dict(B_G=16, L_C=8, U_C=8, L_D=4, U_D=12)
+
+
+def run(use_graph, steps=4, sizes=SMALL):
     tr = G.fresh_trainer(G.make_config(sizes, USE_HIP_GRAPH=use_graph, SEED=3))
     tr.set_hyper(lambda_1=0.3, lambda_2=0.5)
     full = dict(S.SIZES, **sizes)
@@ -34,3 +36,18 @@ def test_graph_replay_equals_eager():
         np.testing.assert_array_equal(p_e[net], p_g[net])
     # dropout / noise differ between iterations (the RNG step advances inside the graph): losses are not constant
     assert len({l[0] for l in l_g}) == len(l_g)
+
+
+def test_graph_replay_equals_eager_at_the_benchmark_sizes():
+    """BASELINE configs[1] (100/50/50/20/80, Training/Train_goodGAN.py:566-572): the launch configurations the bench line runs
+    (128x128 tiles with fused column sums, split filter gradients, batched preps / draws).  Replay == eager bit for bit, and a second
+    replayed run reproduces the first (no atomics-order or uninitialised-scratch dependence in any result)."""
+    sizes = dict(S.SIZES)
+    l_e, p_e, _ = run(False, 3, sizes)
+    l_g, p_g, g_g = run(True, 3, sizes)
+    l_h, p_h, _ = run(True, 3, sizes)
+    assert all(h is not None for h in g_g['full'])
+    assert l_e == l_g == l_h and all(np.isfinite(v) for l in l_g for v in l)
+    for net in p_e:
+        np.testing.assert_array_equal(p_e[net], p_g[net])
+        np.testing.assert_array_equal(p_g[net], p_h[net])
