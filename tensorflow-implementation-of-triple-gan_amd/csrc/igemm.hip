@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
         for (int r = 0; r < 16; ++r) {
           int c = c0 + wc0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           int n = n0 + wn0 + ni * 32 + col;
-          out[(int64_t)c * d.c_out + n] = acc[mi][ni][r];
+          if (c < d.ld_in && n < d.c_out) out[(int64_t)c * d.c_out + n] = acc[mi][ni][r];
         }
   }
 }
@@ -675,7 +675,7 @@ int check_desc(const tg_igemm_desc* d) {
 template <int BM, int BN, int WM_, int WN_>
 static void launch_igemm(IgemmParams& p, hipStream_t s, bool bf16) {
   p.m_tiles = (p.M + BM - 1) / BM;
-  p.n_tiles = p.c_out / BN;
+  p.n_tiles = (p.c_out + BN - 1) / BN;      // the last column tile may overhang: filter rows >= c_out read zeros / unused data, stores are masked by n_store
   const dim3 grid(p.m_tiles * p.n_tiles * p.n_sub);
   if (bf16) {
     if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, true>), grid, dim3(256), 0, s, p);
@@ -761,12 +761,14 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
   int max_taps = 0;
   for (int i = 0; i < n_desc; ++i) max_taps = descs[i].n_taps > max_taps ? descs[i].n_taps : max_taps;
   for (const Cand& c : cands) {
-    if (d->c_out % c.bn) continue;
+    // a tile may overhang the last columns (c_out = 544 = 8.5 x 64: nine 64-column tiles instead of seventeen 32-column ones); the
+    // quantisation below charges the idle columns
+    if (d->c_out % c.bn && c.bn > d->c_out) continue;
     if (force && (c.bm != fbm || c.bn != fbn)) continue;
     bool seg_ok = true;                                      // COLSUM: a tile may straddle at most one application boundary
     for (int i = 0; colsum && i < nseg; ++i) seg_ok = seg_ok && seg_rows[i] >= c.bm;
     if (!seg_ok) continue;
-    const int64_t per_sub = (int64_t)((p.M + c.bm - 1) / c.bm) * (d->c_out / c.bn);
+    const int64_t per_sub = (int64_t)((p.M + c.bm - 1) / c.bm) * ((d->c_out + c.bn - 1) / c.bn);
     // K-tiles per CU: whole rounds for one problem; for the unequal sub-problems of a stride-2 launch (4/6/6/9 taps of a 5x5
     // transposed conv) the longest workgroup bounds the launch from below, which is what pushes those to small tiles
     double iters;
@@ -860,8 +862,8 @@ extern "C" int tg_igemm_bf16(const tg_igemm_desc* d, const float* in, const floa
 
 template <int CT, int NT, int WC, int WN, int WK>
 static void launch_wgrad(WgradParams& p, hipStream_t s, bool bf16) {
-  p.c_tiles = p.d.ld_in / CT;
-  p.n_tiles = p.d.c_out / NT;
+  p.c_tiles = (p.d.ld_in + CT - 1) / CT;      // last tiles may overhang (masked at the store)
+  p.n_tiles = (p.d.c_out + NT - 1) / NT;
   int blocks = p.n_split * p.d.n_taps * p.c_tiles * p.n_tiles;
   if (bf16) hipLaunchKernelGGL((wgrad_f32_kernel<CT, NT, WC, WN, WK, true>), dim3(blocks), dim3(256), 0, s, p);
   else hipLaunchKernelGGL((wgrad_f32_kernel<CT, NT, WC, WN, WK, false>), dim3(blocks), dim3(256), 0, s, p);
@@ -887,8 +889,10 @@ static int wgrad_impl(const tg_igemm_desc* d, const float* in, const float* dout
            bf16 ? " bf16" : "");
   tg::ProfScope prof(tg::PC_WGRAD, flops, bytes, tg::as_stream(stream), desc);
   hipStream_t s = tg::as_stream(stream);
-  const int ct = d->ld_in % 128 == 0 ? 128 : (d->ld_in % 64 == 0 ? 64 : 32);
-  const int nt = d->c_out % 128 == 0 ? 128 : (d->c_out % 64 == 0 ? 64 : 32);
+  // widest tile that divides the dimension; odd multiples of 32 from 160 on (288 = 256 + 32 label channels, 544, 160) take 64-wide
+  // tiles with an overhanging last one instead of 32-wide ones (tg/ops.py:wgrad_splits mirrors this)
+  auto pick = [](int n) { return n % 128 == 0 ? 128 : ((n % 64 == 0 || n >= 160) ? 64 : 32); };
+  const int ct = pick(d->ld_in), nt = pick(d->c_out);
   if (ct == 128 && nt == 128) launch_wgrad<128, 128, 2, 2, 1>(p, s, bf16);
   else if (ct == 128 && nt == 64) launch_wgrad<128, 64, 2, 2, 1>(p, s, bf16);
   else if (ct == 128 && nt == 32) launch_wgrad<128, 32, 4, 1, 1>(p, s, bf16);

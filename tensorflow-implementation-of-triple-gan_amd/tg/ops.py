@@ -77,9 +77,9 @@ def _run_prep_plan(cx, plan):
 def wgrad_splits(desc, m):
     """pixel splits of tg_wgrad_f32: fill ONE round of the 512 resident workgroups (256 CUs x 2) as fully as possible —
     576 blocks take two rounds and run at 56 % — with at least 128 pixels (4 K-tiles) per split."""
-    ct = 128 if desc.ld_in % 128 == 0 else (64 if desc.ld_in % 64 == 0 else 32)
-    nt = 128 if desc.c_out % 128 == 0 else (64 if desc.c_out % 64 == 0 else 32)
-    tiles = desc.n_taps * (desc.ld_in // ct) * (desc.c_out // nt)
+    pick = lambda n: 128 if n % 128 == 0 else (64 if (n % 64 == 0 or n >= 160) else 32)     # csrc/igemm.hip:wgrad_impl
+    ct, nt = pick(desc.ld_in), pick(desc.c_out)
+    tiles = desc.n_taps * -(-desc.ld_in // ct) * -(-desc.c_out // nt)
     return max(1, min(512 // tiles, m // 128))
 
 

@@ -49,6 +49,8 @@ CONV_CASES = [  # n,h,w,cin,cout,k,stride,pad
     (4, 8, 8, 96, 64, 3, 1, 'VALID'),
     (2, 6, 6, 64, 96, 1, 1, 'SAME'),        # NiN
     (7, 9, 7, 40, 32, 3, 2, 'SAME'),        # ragged sizes, M not a tile multiple
+    (3, 8, 8, 138, 138, 3, 1, 'SAME'),      # 160 padded channels both ways: 64-wide tiles whose last one overhangs (columns and reduction rows)
+    (2, 16, 16, 266, 96, 3, 2, 'SAME'),     # 288 = 4.5 x 64 reduction channels, 96 = 1.5 x 64 columns
 ]
 
 
