@@ -1044,6 +1044,7 @@ int tg_bn_train_bwd_f32(const float* dy, int ld_dy, const float* x, int ld_x, fl
 int tg_bn_finalize_f32(const float* s1, const float* s2, int rows, int c, const float* gamma, const float* beta, float eps, float* scale,
                        float* shift, float* mean_inv, float* moving_mean, float* moving_var, float decay, int bessel, void* stream) {
   TG_REQUIRE(s1 && s2 && gamma && beta && scale && shift && mean_inv, "bn_finalize: null buffer");
+  TG_REQUIRE(rows > 0 && c > 0, "bn_finalize: rows=%d c=%d (statistics of an empty batch are undefined)", rows, c);
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_NORM, 0, 0, s);
   hipLaunchKernelGGL(bn_finalize, dim3((c + 127) / 128), dim3(128), 0, s, s1, s2, rows, c, gamma, beta, eps, scale, shift, mean_inv, moving_mean,
@@ -1065,6 +1066,7 @@ int tg_bn_eval_finalize_f32(int c, const float* gamma, const float* beta, const 
 int tg_bn_bwd_finalize_f32(const float* s_dy, const float* s_dyx, int rows, int c, const float* gamma, const float* mean_inv, float* abc,
                            float* dgamma, float* dbeta, void* stream) {
   TG_REQUIRE(s_dy && s_dyx && gamma && mean_inv && abc && dgamma && dbeta, "bn_bwd_finalize: null buffer");
+  TG_REQUIRE(rows > 0 && c > 0, "bn_bwd_finalize: rows=%d c=%d", rows, c);
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_NORM, 0, 0, s);
   hipLaunchKernelGGL(bn_bwd_finalize, dim3((c + 127) / 128), dim3(128), 0, s, s_dy, s_dyx, rows, c, gamma, mean_inv, abc, dgamma, dbeta);

@@ -481,6 +481,7 @@ int tg_wn_bwd_tab_f32(const float* dw, const float* v, const float* g, int t, in
 /* coef: scratch of 2*c floats */
 int tg_wn_bwd_f32(const float* dw, const float* v, const float* g, int rows, int c, float* dv, float* dg, float* coef, void* stream) {
   TG_REQUIRE(dw && v && g && dv && dg && coef, "wn_bwd: null buffer");
+  TG_REQUIRE(rows > 0 && c > 0, "wn_bwd: rows=%d c=%d", rows, c);
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_PREP, 0, 4.0 * rows * c * 5, s);
   hipLaunchKernelGGL(wn_bwd_cols, dim3((c + 31) / 32), dim3(1024), 0, s, dw, v, g, rows, c, dg, coef);
