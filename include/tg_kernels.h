@@ -322,6 +322,33 @@ int tg_c_loss_f32(const float* c_logits, int ld, int n_real, int n_unl, int n_re
 int tg_feature_match_f32(const float* f_fake, int n_fake, const float* f_unl, int n_unl, int c, float* df_fake, float* df_unl, float* loss,
                          void* stream);
 int tg_pull_away_f32(const float* f, int n, int c, int masked, float* scratch /* n*c+n*n+n floats */, float* df, float* loss, void* stream);
+/* ---- loss variants of Training/train_base.py:156-574 (_loss_BGAN, _loss_GoodBadGAN, _loss_GoodRegGAN[_cifar10|_BS|_BS_cifar10],
+ * _loss_GoodRegBadGAN; SURVEY §8f N4 — no trainer of the reference repository calls them).  They are weighted sums of the terms
+ * above plus the two below; Training/train_base.py of the package composes them. */
+/* tg_d_loss_f32 that also reports terms[3] = {BCE(real,1), .5 BCE(fake,0), .5 BCE(unl,0)} (the lists train_base.py:304 returns). */
+int tg_d_loss_terms_f32(const float* logits, int ld, int n_real, int n_fake, int n_unl, float* dlogits, int ld_d, float* loss, float* terms,
+                        void* stream);
+/* tg_c_loss_f32 with explicit HOST weights[6] = {CE(real), c_unl, H(unl), Bal(unl), CE(fake), MSE(unl,rep)} (_loss_GAN: {1, .005,
+ * 1e-6, 1e-3, l1, l2}); n_fake may be 0 (then y_fake may be NULL), d_unl_logits may be NULL when weights[1] == 0.
+ * terms (optional, device [6]): the unweighted term values in the same order. */
+int tg_c_loss_terms_f32(const float* c_logits, int ld, int n_real, int n_unl, int n_rep, int n_fake, const float* y_real, const float* y_fake,
+                        const float* d_unl_logits, int ld_dunl, const float* weights, float* dlogits, int ld_d, float* loss, float* terms,
+                        void* stream);
+/* bad-GAN "true-fake" terms (train_base.py:162-166,226-229,296-298), lse = logsumexp_k(logits):
+ *   T_unl = mean(-.5 lse + .5 softplus(lse)) over the unlabelled rows, T_fake = .5 mean softplus(lse) over the bad generator's rows;
+ * loss[3] = {w_unl T_unl + w_fake T_fake, T_unl, T_fake}; the gradients are written to d_unl / d_fake or, accumulate_* != 0, added. */
+int tg_true_fake_loss_f32(const float* unl_logits, int ld_u, int n_unl, const float* fake_logits, int ld_f, int n_fake, float w_unl, float w_fake,
+                          float* d_unl, int ld_du, int accumulate_unl, float* d_fake, int ld_df, int accumulate_fake, float* loss, void* stream);
+/* T = mean_n sum_k (a - b)^2 (train_base.py:299); loss[2] = {w T, T}; da / db (either may be NULL) written or added. */
+int tg_sqdiff_rows_loss_f32(const float* a, int ld_a, const float* b, int ld_b, int n, int k, float w, float* da, int ld_da, int accumulate_a,
+                            float* db, int ld_db, int accumulate_b, float* loss, void* stream);
+/* minibatch discrimination (Model/modle_base.py:110-128): act = x @ W viewed [n][kernels][dim] (dim <= 8);
+ * out[i] = [x[i,:c], f[i,:], 0...] with f[i,k] = sum_j exp(-sum_d |act[i,k,d] - act[j,k,d]|) + b[k].
+ * bwd: df = the gradient's columns c.. ([n][kernels], stride ld_df) -> dact (pads zeroed), db[k] = sum_i df[i,k] (db may be NULL). */
+int tg_minibatch_disc_fwd_f32(const float* act, int ld_a, const float* x, int ld_x, int c, const float* b, float* out, int ld_out, int n, int kernels,
+                              int dim, void* stream);
+int tg_minibatch_disc_bwd_f32(const float* act, int ld_a, const float* df, int ld_df, float* dact, int ld_da, float* db, int n, int kernels, int dim,
+                              void* stream);
 /* counters[0] += #correct, counters[1] += n (tf.metrics.accuracy, Training/Train_goodGAN.py:428-447). */
 int tg_accuracy_count_f32(const float* logits, int ld, const float* labels, int n, int k, float* counters, void* stream);
 

@@ -83,7 +83,11 @@ class Good_GAN(model_base.NN_Base):
                                       ('d_h2_wnconv0', 128, k), ('d_h2_wnconv1', 128, 2 * k)):
                 wn(d, D + name, (3, 3, cin + extra, cout))
                 cin = cout
-            wn(d, D + 'd_h3_wndense', (cin + k, 1))
+            if getattr(self.config, 'MINIBATCH_DIS', False):                              # Good_GAN.py:159-162
+                d += [(D + 'w', (cin + k, 100 * 5), True, 'xavier'), (D + 'b', (100,), True, 0.)]
+                dense(d, D + 'd_h3_lin/d_h3_lin', cin + k + 100, 1)
+            else:
+                wn(d, D + 'd_h3_wndense', (cin + k, 1))
             cin = 3
             for name, bname, cout in (('c_h0_conv0', 'c_h0_bn0', 128), ('c_h0_conv1', 'c_h0_bn1', 128), ('c_h0_conv2', 'c_h0_bn2', 128),
                                       ('c_h1_conv0', 'c_h1_bn0', 256), ('c_h1_conv1', 'c_h1_bn1', 256), ('c_h1_conv2', 'c_h1_bn2', 256),
@@ -113,6 +117,9 @@ class Good_GAN(model_base.NN_Base):
                     st.set(name, 0.02 + _trunc_normal(rng, shape))
                 elif init == 'n05':
                     st.set(name, 0.05 * rng.standard_normal(shape))
+                elif init == 'xavier':                                   # tf.contrib.layers.xavier_initializer(): uniform, fan_avg
+                    lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+                    st.set(name, rng.uniform(-lim, lim, shape))
                 else:
                     st.set(name, np.full(shape, init, np.float32))
             cx.stores[net] = st
@@ -175,8 +182,9 @@ class Good_GAN(model_base.NN_Base):
             h2 = ops.cond_concat(h2, _twice(y), 2 * y.c)                                        # y is concatenated twice (:151-153)
             h2 = self._WN_conv2d(h2, 128, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h2_wnconv1", activation=lre)
             h3 = ops.global_avgpool_concat(h2, y.t, y.c)                                        # reduce_mean + concat y
-            if self.config.MINIBATCH_DIS:
-                raise NotImplementedError("MINIBATCH_DIS is off in every config of the reference (Train_goodGAN.py:502,578,656)")
+            if self.config.MINIBATCH_DIS:                                                      # :159-162 (off in every config of the reference)
+                h3 = self._minibatch_discrimination(h3, 100, concat_input=True)               # f = ...; h3 = tf.concat([h3, f], 1)
+                return None, self._linear_fc(h3, 1, 'd_h3_lin', narrow=True)
             return None, self._WN_dense(h3, 1, 'd_h3_wndense', narrow=True)
 
     def classifier(self, image, train_ph, reuse=False, segments=None):

@@ -141,6 +141,16 @@ class NN_Base(object):
                                 bias_grad=cx.var_grad('b') if tr else None, narrow_out=narrow,
                                 wn=(cx.var('g'), cx.var_grad('g') if tr else None))
 
+    def _minibatch_discrimination(self, input, num_kernels, dim_per_kernel=5, name="minibatch_discrim", concat_input=False):
+        """modle_base.py:110-128: variables `w` [features, num_kernels*dim_per_kernel] (Xavier) and `b` [num_kernels] of the enclosing
+        variable scope (tf.name_scope does not prefix tf.get_variable).  concat_input (extension): return concat([input, f], 1), the
+        only use the reference makes of the result (Good_GAN.py:160-161), from the same launch."""
+        cx = ctx()
+        tr = cx.trains()
+        return ops.minibatch_discrimination(input, cx.var('w'), cx.var('b'), num_kernels, dim_per_kernel,
+                                            w_grad=cx.var_grad('w') if tr else None, b_grad=cx.var_grad('b') if tr else None,
+                                            concat_input=concat_input)
+
     def _nin(self, input, num_units, name, activation=None):
         """network-in-network (1x1 conv): reshape + _WN_dense + reshape (modle_base.py:204-209)."""
         return self._WN_dense(input, num_units, name, activation=activation)

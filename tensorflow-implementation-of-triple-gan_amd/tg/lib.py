@@ -70,6 +70,8 @@ def _ctype_of(decl):
             return C.POINTER(C.c_int32)
         if name == "state":
             return C.c_void_p
+        if name == "weights":                      # HOST float array (tg_c_loss_terms_f32)
+            return C.POINTER(C.c_float)
         if name in ("ms", "flops", "bytes"):
             return C.POINTER(C.c_double)
         if name == "launches":

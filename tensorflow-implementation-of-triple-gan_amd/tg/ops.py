@@ -516,6 +516,33 @@ def global_avgpool_concat(x, y_onehot_t, ncls):
     return out
 
 
+def minibatch_discrimination(x, w, b, num_kernels, dim, w_grad=None, b_grad=None, concat_input=False):
+    """NN_Base._minibatch_discrimination (Model/modle_base.py:110-128) on a dense [n, c] activation: A = x @ W (a 1-tap MFMA product),
+    f[i,k] = sum_j exp(-|A[i,k,:] - A[j,k,:]|_1) + b[k].  Returns f, or concat([x, f], 1) when concat_input (what the SVHN
+    discriminator does with it, Model/Good_GAN.py:160-161)."""
+    cx = ctx()
+    holder = {}
+    skip = concat_input and cx.tape is not None and x.requires_grad
+    if skip:
+        def bwd_skip():      # recorded BEFORE the product, so it runs after the product's input gradient has been written to x.grad
+            g, gx = holder['g'], cx.grad_of(x)
+            _call('tg_pad_add_f32', gx.ptr, gx.ld, x.c, g.ptr, g.ld, gx.ptr, gx.ld, x.rows, cx.stream)
+        cx.record(bwd_skip)
+    a = conv2d(x, w, None, num_kernels * dim, 1, 1, 'SAME', kernel_grad=w_grad)
+    c0 = x.c if concat_input else 0
+    out = cx.new_act(x.n, 1, 1, c0 + num_kernels, pad32(c0 + num_kernels), requires_grad=a.requires_grad)
+    _call('tg_minibatch_disc_fwd_f32', a.ptr, a.ld, x.ptr, x.ld, c0, _p(b), out.ptr, out.ld, x.n, num_kernels, dim, cx.stream)
+    if cx.tape is not None and a.requires_grad:
+        def bwd():
+            g = out.grad
+            holder['g'] = g
+            ga = cx.grad_of(a)
+            _call('tg_minibatch_disc_bwd_f32', a.ptr, a.ld, C.c_void_p(g.t.data_ptr() + 4 * c0), g.ld, ga.ptr, ga.ld, _p(b_grad), x.n, num_kernels,
+                  dim, cx.stream)
+        cx.record(bwd)
+    return out
+
+
 def argmax_onehot(logits, k):
     cx = ctx()
     out = cx.scratch('oh', logits.n * k)

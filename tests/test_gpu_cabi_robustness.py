@@ -42,6 +42,8 @@ for m in re.finditer(r"(?:const char\*|int64_t|int)\s+(tg_\w+)\s*\(([^;{{]*?)\)\
             vals.append(C.byref(desc))
         elif t == C.POINTER(C.c_int32):
             vals.append(host)
+        elif t == C.POINTER(C.c_float):
+            vals.append((C.c_float * 8)())
         elif t in (C.c_float,):
             vals.append(0.0)
         else:
