@@ -132,7 +132,18 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
 #endif
   const int per_sub = p.m_tiles * p.n_tiles;
   const int lid = xcd_remap(blockIdx.x, per_sub * p.n_sub);
-  const int sub = lid / per_sub, rem_id = lid - sub * per_sub;
+  // Several sub-problems (the 9/6/6/4-tap parities of a stride-2 transposed conv): tile-major, sub-problem-minor, and the order of
+  // the sub-problems rotates every 32 workgroups.  Workgroups go to the 32 compute units of an XCD round-robin, all resident at once
+  // for these small launches, so with a fixed order unit j would get sub-problem j % n_sub every time (measured: the units holding
+  // only 9-tap workgroups finish at 190 us, the median at 100); rotating gives every unit the same mix.
+  int sub, rem_id;
+  if (p.n_sub > 1 && 32 % p.n_sub == 0) {
+    rem_id = lid / p.n_sub;
+    sub = (lid + (lid >> 5)) % p.n_sub;
+  } else {
+    sub = lid / per_sub;
+    rem_id = lid - sub * per_sub;
+  }
   const SubDesc& d = p.d[sub];
   const int nt = rem_id % p.n_tiles, mt = rem_id / p.n_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -775,7 +786,9 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
     if (n_desc == 1) {
       iters = (double)((per_sub + 255) / 256) * max_taps;
     } else {
-      const double total = (double)per_sub * taps / 256.0;
+      // the sub-problems are mixed over the compute units (rotating order, see the kernel): a unit's load is the mean plus about half
+      // of the longest workgroup — measured on the generator's layers: 64x64 tiles 0.124 ms, 64x128 0.153 ms, equal mean load
+      const double total = (double)per_sub * taps / 256.0 + 0.5 * max_taps;
       iters = total > max_taps ? total : max_taps;
     }
     const double t = iters * c.bm * c.bn / c.eff;
