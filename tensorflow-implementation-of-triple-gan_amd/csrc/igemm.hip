@@ -763,7 +763,15 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
   // time ~ ceil(tiles / 256 CUs) * tile area / efficiency.  520 tiles of 128x128 cost 3 tile-times per CU, the same
   // problem in 64x64 tiles costs ceil(2080/256) = 9 quarter-size ones.  eff: measured on the classifier layers (N = 250).
   struct Cand { int bm, bn; double eff; };
-  static const Cand cands[] = {{128, 128, 1.00}, {64, 128, 0.97}, {64, 64, 0.96}, {128, 64, 0.95}, {32, 128, 0.85}, {128, 32, 0.70}};
+  static Cand cands[] = {{128, 128, 1.00}, {64, 128, 0.97}, {64, 64, 1.02}, {128, 64, 0.95}, {32, 128, 0.85}, {128, 32, 0.70}};
+  static bool eff_env = false;
+  // 64x64 at 1.02: with up to four co-resident workgroups per compute unit their prologues / epilogues interleave, whereas the two
+  // 128x128 ones run in lockstep (workgroup timeline: both start and end within 0.2 us) and expose theirs — measured on the bench line
+  // 0.96 -> 1.02: +0.6 % (the 32x32 128-channel layers move to 64x64 tiles); 1.06 / 1.12 bring nothing more.
+  if (!eff_env) {                                         // tuning aid: TG_IGEMM_EFF64 overrides the 64x64 entry
+    eff_env = true;
+    if (const char* e = getenv("TG_IGEMM_EFF64")) cands[2].eff = atof(e);
+  }
   int bm = 128, bn = 32;
   double best = 1e300;
   const char* force = getenv("TG_IGEMM_TILE");     // "bm,bn" — tuning aid
