@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Triple-GAN training throughput on MI355X: images/sec of the full D+G+C step (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts the N ranks itself, tg/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one iteration of Training/Train_goodGAN.py:266-276 (D-update, G-update, C-update + EMA) on the CIFAR-10
@@ -16,8 +16,8 @@ The JSON line also carries
                  region (the timed region replays hipGraphs, whose inner kernels cannot be bracketed by events);
                  peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).  The figure over ALL igemm / wgrad launches
                  (generator, discriminator, dense, ZCA included) is reported next to it.
-  cpu_baseline — the NumPy oracle (oracle/step_cifar10.py, a port: TF1 is not installable) timed on this host's cores
-                 for one iteration of the same workload (rank 0, N = 1 only).
+  cpu_baseline — the NumPy oracle (oracle/step_cifar10.py, a port: TF1 is not installable) timed on this host's cores:
+                 1 warm-up + 3 timed iterations of the same workload, median (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -102,30 +102,88 @@ def make_config(rank):
     return TempConfig()
 
 
-def cpu_baseline_one_iteration():
-    """the oracle as the CPU baseline ('port'): one iteration = 100 nominal images."""
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([int(i.get('num_threads', 1)) for i in threadpool_info() if i.get('user_api') == 'blas'] or [1])
+    except Exception:
+        return None
+
+
+def cpu_baseline(warmup=1, timed=3):
+    """the oracle as the CPU baseline ('port'; BASELINE.md §3 protocol, bounded): `warmup` untimed + `timed` timed iterations of the
+    bench workload (one iteration = 100 nominal images), free-running from the same initial weights; value = 100 / median time."""
     from oracle import step_cifar10 as S
-    P = S.init_params(0)
-    st = S.new_state(P)
+    st = S.new_state(S.init_params(0))
     zca = S.synth_zca()
-    batch, rnd = S.synth_batch(1), S.synth_rnd(2)
     hyper = dict(lr=3e-4, cla_lr=3e-3, beta1=0.5, lambda_1=0.3, lambda_2=0.5)
-    t0 = time.perf_counter()
-    S.train_step(st, batch, rnd, hyper, zca)
-    dt = time.perf_counter() - t0
-    return dict(value=SIZES['B_G'] / dt, unit="images/sec", cores=os.cpu_count(), kind="port",
-                sample="1 iteration (100 nominal images, 1464 GFLOP) of the same CIFAR-10 workload, NumPy/BLAS fp32 oracle, %.1f s" % dt)
+    times = []
+    for i in range(warmup + timed):
+        batch, rnd = S.synth_batch(1 + i), S.synth_rnd(100 + i)
+        t0 = time.perf_counter()
+        S.train_step(st, batch, rnd, hyper, zca)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times[warmup:]))
+    threads = _blas_threads()
+    return dict(value=round(SIZES['B_G'] / med, 3), unit="images/sec", cores=threads or os.cpu_count(), kind="port",
+                host_logical_cpus=os.cpu_count(), blas_threads=threads, cpu_model=_cpu_model(),
+                seconds_per_iteration=[round(t, 2) for t in times],
+                sample="%d warm-up + %d timed iterations (median %.1f s) of the same CIFAR-10 bs=100 workload (100 nominal images, 1464 GFLOP "
+                       "each), NumPy/BLAS fp32 oracle (TF1 unobtainable)" % (warmup, timed, med))
+
+
+def _sha256(path):
+    import hashlib
+    return hashlib.sha256(open(path, 'rb').read()).hexdigest()
+
+
+def measured_traffic():
+    """HBM bytes of the dominant launch from the PMC passes stored under profiles/ (rocprofv3 cannot run inside this process).  The
+    record names the kernel source it was collected for (sha256 of csrc/igemm.hip): for any other source the figure is stale and
+    `traffic` is null."""
+    for name in ('r02_traffic.json', 'r01_traffic.json'):
+        tfile = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(tfile):
+            continue
+        rec = json.load(open(tfile))
+        tj = rec['dominant_launch']
+        want = rec.get('igemm_hip_sha256')
+        have = _sha256(os.path.join(PKG, 'csrc', 'igemm.hip'))
+        if want != have:
+            return None, dict(stale='profiles/%s was collected for another csrc/igemm.hip (%s...), this build has %s...: re-run '
+                                    'tools/pmc_traffic.sh' % (name, str(want)[:12], have[:12]))
+        return tj['traffic_bytes_corrected'], dict(
+            algorithmic_bytes_per_launch=tj['algorithmic_bytes'], kernel=tj['kernel'], igemm_hip_sha256=have,
+            source='profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950-corrected)' % name)
+    return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--steps', type=int, default=150)      # ~2.4 s timed at 16 ms/step
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying hipGraphs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--prof-iters', type=int, default=2)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # no launcher above us: start the N ranks here.  This process has made no GPU call (it only counts devices) and stays the
+        # parent; rank 0's JSON line goes straight to our stdout.
+        from tg import launch
+        raise SystemExit(launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
 
     import torch
     from tg import dist as tgdist
@@ -135,12 +193,16 @@ def main():
     from Input_Pipeline.syntheticDataset import syntheticDataset
 
     world, rank, local = tgdist.env_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (or drop WORLD_SIZE and let bench.py spawn them)" % (args.gpus, world))
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("rank %d needs HIP device %d, %d visible" % (rank, local, torch.cuda.device_count()))
     cfg = make_config(rank)
     cfg.USE_HIP_GRAPH = not args.no_graph
     tr = Train(cfg, None, None)
     tr._build_train_graph(Good_GAN_cifar10)
+    if tr.world != args.gpus or tgdist.world_size() != args.gpus or tgdist.rccl_ranks() != args.gpus:
+        raise SystemExit("asked for %d replicas, the exchange has %d (communicator: %d)" % (args.gpus, tgdist.world_size(), tgdist.rccl_ranks()))
     tr.set_hyper(lambda_1=cfg.FAKE_G_LAMBDA, lambda_2=0.5)       # the late-training schedule: every loss term active
     cx = tr.cx
 
@@ -221,14 +283,7 @@ def main():
     ig = classes['igemm_f32']
     achieved = fl['executed_igemm'] / (ig['ms_per_iter'] * 1e-3) / 1e12
     n_conv_launches = (conv_n['igemm_f32'] + conv_n['wgrad_f32']) / args.prof_iters
-    # HBM bytes of the dominant launch from the PMC passes stored under profiles/ (rocprofv3 cannot run inside this process)
-    traffic, traffic_detail = None, None
-    tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-    if os.path.exists(tfile):
-        tj = json.load(open(tfile))['dominant_launch']
-        traffic = tj['traffic_bytes_corrected']
-        traffic_detail = dict(algorithmic_bytes_per_launch=tj['algorithmic_bytes'], kernel=tj['kernel'],
-                              source='profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950-corrected)')
+    traffic, traffic_detail = measured_traffic()
     roofline = dict(bound="mfma", kernel="classifier 3x3 conv path: igemm_f32_kernel (fwd + input grad) + wgrad_f32_kernel",
                     achieved=round(conv_tf, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(conv_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                     traffic=traffic, traffic_detail=traffic_detail, launches_per_step=n_conv_launches,
@@ -248,6 +303,8 @@ def main():
             "value": round(args.steps * SIZES['B_G'] * world / dt, 2),
             "unit": "images/sec",
             "n_gpus": world,
+            "rccl_ranks": tgdist.rccl_ranks(),
+            "dist_backend": tgdist.backend_name(),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -264,7 +321,7 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_one_iteration()
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     tgdist.barrier()
     tgdist.shutdown()

@@ -9,7 +9,9 @@ TensorFlow name, in ONE file `model_<epoch>.ckpt.npz` (so `_findfilename`'s name
     <variable>/Adam_optimizer_1              Adam second-moment slot v
     <variable>/ExponentialMovingAverage      EMA shadow of the classifier variables             (Train_goodGAN.py:101-103)
     tg/adam_step/<network>                   step count t of that network's optimiser (TF keeps beta1_power = beta1^t, beta2_power)
-    tg/rng_state                             Philox (seed, step) — TF's graph-level seeds have no equivalent
+    tg/rng_state                             Philox (seed, step) of the writing rank — TF's graph-level seeds have no equivalent.  On
+                                             restore every rank takes the STEP and keeps its own seed (replicas draw different
+                                             z / y / masks / noise: config.SEED + 7919 * rank, Train.__init__)
     tg/epoch                                 epoch the file was written after
 
 Save gathers from the flat device buffers; restore scatters back — the MFMA-side filter layouts are rebuilt from the values every
@@ -53,7 +55,8 @@ def state_dict(stores, rng=None, epoch=0):
     return out
 
 
-def load_state_dict(stores, d, rng=None, strict=True):
+def load_state_dict(stores, d, rng=None, strict=True, keep_seed=False):
+    """keep_seed: restore only the RNG's step counter (data-parallel resume: the file holds rank 0's seed)."""
     import torch
     missing = []
     for net, st in stores.items():
@@ -75,7 +78,11 @@ def load_state_dict(stores, d, rng=None, strict=True):
         else:
             missing.append(k)
     if rng is not None and hasattr(rng, 'state') and 'tg/rng_state' in d:
-        rng.state.copy_(torch.from_numpy(np.asarray(d['tg/rng_state']).astype(np.int64)))
+        saved = torch.from_numpy(np.asarray(d['tg/rng_state']).astype(np.int64))
+        if keep_seed:
+            rng.state[1:2].copy_(saved[1:2])
+        else:
+            rng.state.copy_(saved)
     if strict and missing:
         raise KeyError("checkpoint lacks %d variables, e.g. %s" % (len(missing), missing[:3]))
     return missing
@@ -105,7 +112,8 @@ class Saver(object):
     def restore(self, sess, dir_names=None, epoch=None):                            # :34-37
         self.save_dir, filename, start_epoch = self._findfilename(dir_names, epoch)
         with np.load(filename + '.npz') as z:
-            load_state_dict(sess.cx.stores, z, sess.cx.rng)
+            # a replica keeps its own seed: with rank 0's every replica would draw the same latents, masks and noise
+            load_state_dict(sess.cx.stores, z, sess.cx.rng, keep_seed=getattr(sess, 'world', 1) > 1)
         return start_epoch
 
     def _findfilename(self, dir_names=None, epoch=None):                            # :39-66

@@ -233,6 +233,12 @@ class Train(Train_base):
         cx = self.cx
         use_graph = getattr(self.config, 'USE_HIP_GRAPH', True) if use_graph is None else use_graph
         use_graph = use_graph and isinstance(cx.rng, PhiloxRNG)
+        if use_graph and not tgdist.graphs_allowed():          # torch's RCCL process group: its watchdog cannot coexist with a capture
+            if not getattr(self, '_warned_eager', False) and self.rank == 0:
+                print("tg: backend %r cannot run beside hipGraph capture (tg/dist.py) - launching eagerly; "
+                      "use TG_DIST_BACKEND=rccl-direct for graphs" % tgdist.backend_name(), flush=True)
+            self._warned_eager = True
+            use_graph = False
         segs = self._segments(pre_train)
         key = 'pre' if pre_train else 'full'
         if self._graphs is None:
@@ -266,14 +272,10 @@ class Train(Train_base):
 
     def _capture(self, segs, graphs, key):
         """Record every segment of one iteration as a hipGraph — all of them back to back, nothing launched and no collective issued
-        in between.  With replicas the process group must be QUIET while a stream captures: on ROCm the RCCL watchdog thread's
-        hipEventQuery on a pending collective fails with hipErrorCapturedEvent during another thread's capture (even in thread-local
-        capture mode) and takes the process down, so the device is drained and the watchdog given time to retire its work list."""
+        in between.  Only reached when tg.dist.graphs_allowed(): the exchange backends used with graphs (rccl-direct, gloo) have no
+        thread that touches HIP events behind the trainer's back, so a capture cannot be disturbed (tg/dist.py docstring)."""
         import ctypes as C
         cx = self.cx
-        if tgdist.quiet_capture_needed():
-            torch.cuda.synchronize()
-            time.sleep(1.0)                              # several of the watchdog's 100 ms sweeps
         cx.prep_cache = {}
         cx.plan_tag = key
         try:

@@ -269,7 +269,10 @@ int tg_ds_open(const char* path, void** handle) {
     const uint8_t* img = nullptr; int64_t il = 0, lab = 0, hh = 0, ww = 0;
     int rc = parse_example(d->base + d->off[0], d->len[0], &img, &il, &lab, &hh, &ww);
     if (rc != TG_OK) { destroy(d); return rc; }
-    if (hh <= 0 || ww <= 0 || il == 0 || il % (hh * ww) != 0) return fail("record 0: image bytes do not match height*width", d->off[0]);
+    // height / width come from the file: bound them before multiplying (2^32 x 2^32 would wrap to 0 and divide by zero below)
+    constexpr int64_t kMaxSide = 1 << 16;
+    if (hh <= 0 || ww <= 0 || hh > kMaxSide || ww > kMaxSide || il <= 0 || hh * ww > il || il % (hh * ww) != 0)
+      return fail("record 0: image bytes do not match height*width", d->off[0]);
     d->h = (int)hh; d->w = (int)ww; d->c = (int)(il / (hh * ww));
   }
   *handle = d;

@@ -105,22 +105,37 @@ class Communicator(object):
         call('tg_broadcast_f32', lib.ptr(t), t.numel(), root, self.handle, lib.cur_stream() if stream is None else stream)
         return t
 
+    def count(self):
+        """(nranks, rank) as the communicator itself reports them (tg_comm_count)."""
+        n, r = C.c_int(), C.c_int()
+        call('tg_comm_count', self.handle, C.byref(n), C.byref(r))
+        return n.value, r.value
+
     def destroy(self):
         if self.handle:
             call('tg_comm_destroy', self.handle)
             self.handle = C.c_void_p()
 
 
-def rendezvous(world, rank, device):
-    """rank 0 draws the communicator id and publishes it in a TCPStore at MASTER_ADDR:MASTER_PORT; every rank joins."""
+def exchange_id(world, rank, make_id, key='tg_comm_id'):
+    """Rendezvous only: rank 0 calls make_id() and publishes the bytes in a TCPStore at MASTER_ADDR:MASTER_PORT, every rank
+    reads them.  Under torchrun the elastic agent already serves a store on that port (TORCHELASTIC_USE_AGENT_STORE=True): every
+    rank then connects as a client, exactly as torch's own env:// rendezvous does.  Returns (id bytes, store)."""
     import datetime
     import torch.distributed as dist
     addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
     port = int(os.environ.get('MASTER_PORT', '29500'))
+    agent = os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True'
+    store = dist.TCPStore(addr, port, world, is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=300))
+    key = '%s/%s' % (os.environ.get('TORCHELASTIC_RUN_ID', 'run'), key)
+    if rank == 0:
+        store.set(key, make_id())
+    return store.get(key), store
+
+
+def rendezvous(world, rank, device):
+    """every rank joins ONE communicator whose id rank 0 draws (exchange_id)."""
     if world == 1:
         return Communicator(1, 0, device, Communicator.unique_id()), None
-    store = dist.TCPStore(addr, port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=300))
-    if rank == 0:
-        store.set('tg_comm_id', Communicator.unique_id())
-    uid = store.get('tg_comm_id')
+    uid, store = exchange_id(world, rank, Communicator.unique_id)
     return Communicator(world, rank, device, uid), store

@@ -1,40 +1,60 @@
-"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL (backend 'nccl' on ROCm) or gloo (CPU
-tests).  The Triple-GAN step shards by image batch: every replica runs the three solver phases on
-its own batch and the three networks' flat gradient buffers are sum-all-reduced once per phase; Adam then applies
-grad/world_size identically on every replica, so weights stay bit-identical."""
+"""Data-parallel plumbing: one process per GPU.  The Triple-GAN step shards by image batch: every replica runs the
+three solver phases on its own batch and the three networks' flat gradient buffers are sum-all-reduced in buckets; Adam then
+applies grad/world_size identically on every replica, so weights stay bit-identical.
+
+Backends (TG_DIST_BACKEND, default 'rccl-direct' on a GPU, 'gloo' on the CPU):
+
+  rccl-direct  RCCL through the C ABI of include/tg_comm.h (libtg_comm.so).  Every collective of the communicator is issued on ONE
+               HIP stream owned by this module (the exchange stream) and ordered against the launch stream with events that only this
+               thread touches: there is no watchdog thread, so nothing polls an event while the launch stream captures a hipGraph.
+               torch.distributed is used for the rendezvous only (a TCPStore carries the communicator id).
+  nccl         torch.distributed's RCCL process group.  Its watchdog thread calls hipEventQuery on every collective still on its
+               work list; on ROCm that query fails with hipErrorCapturedEvent while ANY stream of the process captures (also in
+               thread-local capture mode) and takes the process down (round 1: gpurun_out/rccl_single_stderr.txt).  This torch build
+               has no call that waits for the watchdog's list to drain, so there is no deterministic way to make a capture safe:
+               with this backend the trainer does not capture graphs (graphs_allowed() is False) and launches eagerly.
+  gloo         CPU tests and the N-ranks-on-one-GPU rehearsal (host-blocking collectives, no watchdog).
+"""
 import os
 
 import torch
 import torch.distributed as dist
 
 
-# TG_DIST_SINGLE=1: create the process group even for ONE replica and run every collective on it — the RCCL code path
-# (communicator bound to the device, asynchronous bucket all-reduce beside a graph launch, broadcast, barrier) exercised on a
-# one-GPU box; results are unchanged (a one-rank sum is the identity).
+# TG_DIST_SINGLE=1: create the communicator / process group even for ONE replica and run every collective on it — the RCCL code
+# path (communicator bound to the device, bucketed exchange on its own stream beside a graph launch, broadcast, barrier) exercised
+# on a one-GPU box; results are unchanged (a one-rank sum is the identity).
 SINGLE = os.environ.get('TG_DIST_SINGLE') == '1'
 
-# TG_DIST_BACKEND=rccl-direct: no torch process group — the collectives are tg_comm.h calls (libtg_comm.so) on the launch stream.
 _direct = None            # tg.comm.Communicator
 _direct_store = None      # keeps the rendezvous TCPStore alive
+_xstream = None           # the exchange stream of the direct backend
 
 
 def env_world():
     return int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
 
 
+def default_backend():
+    return os.environ.get('TG_DIST_BACKEND') or ('rccl-direct' if torch.cuda.is_available() else 'gloo')
+
+
 def init(backend=None):
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  Returns (world, rank, local_rank)."""
-    global _direct, _direct_store
+    global _direct, _direct_store, _xstream
     world, rank, local = env_world()
     if (world > 1 or SINGLE) and not dist.is_initialized() and _direct is None:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = os.environ.get('TG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+            backend = default_backend()
         if backend == 'rccl-direct':
             from . import comm
+            if torch.cuda.device_count() <= local:
+                raise RuntimeError("rank %d wants HIP device %d but only %d are visible" % (rank, local, torch.cuda.device_count()))
             torch.cuda.set_device(local)
             _direct, _direct_store = comm.rendezvous(world, rank, local)
+            _xstream = torch.cuda.Stream(device=local)
             return world, rank, local
         if 'TG_DEVICE_INDEX' in os.environ:        # rehearsal of N ranks on one GPU (gloo): every rank uses this device
             local = int(os.environ['TG_DEVICE_INDEX'])
@@ -55,6 +75,19 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def backend_name():
+    if _direct is not None:
+        return 'rccl-direct'
+    return dist.get_backend() if dist.is_initialized() else None
+
+
+def rccl_ranks():
+    """number of ranks the RCCL communicator itself reports (tg_comm_count / the process group's size); 1 without one."""
+    if _direct is not None:
+        return _direct.count()[0]
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
 def active():
     """collectives are issued: more than one replica (or the one-replica RCCL rehearsal)."""
     if _direct is not None:
@@ -62,10 +95,9 @@ def active():
     return dist.is_initialized() and (dist.get_world_size() > 1 or SINGLE)
 
 
-def quiet_capture_needed():
-    """a process group's watchdog thread polls events of pending collectives — it must be idle while a stream captures
-    (Training/Train_goodGAN.py:_capture).  The direct backend has no such thread."""
-    return active() and _direct is None
+def graphs_allowed():
+    """May the trainer capture hipGraphs while this backend is active?  Not with the 'nccl' process group (module docstring)."""
+    return not (dist.is_initialized() and dist.get_backend() == 'nccl')
 
 
 def rank():
@@ -74,30 +106,48 @@ def rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
 
-def allreduce_sum_(flat):
-    """in-place sum over replicas of a flat gradient buffer (one collective per network per iteration)."""
-    if active():
-        if _direct is not None:
-            return _direct.allreduce_sum_(flat)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    return flat
+class _StreamWork(object):
+    """handle of a collective issued on the exchange stream: `done` is recorded behind it."""
+    __slots__ = ('done',)
+
+    def __init__(self, done):
+        self.done = done
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.done)
+
+
+def _on_xstream(fn):
+    """run fn(stream handle) on the exchange stream after everything the current stream has enqueued so far."""
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream())
+    _xstream.wait_event(ready)
+    fn(_xstream.cuda_stream)
+    done = torch.cuda.Event()
+    done.record(_xstream)
+    return _StreamWork(done)
 
 
 def allreduce_sum_async_(flat):
-    """Start the in-place sum on RCCL's own stream — it waits for what the current stream has enqueued so far and runs beside
-    whatever is enqueued next (the remaining backward pass).  Returns a handle for wait_(); None on one replica."""
-    if active():
-        if _direct is not None:                     # stream-ordered on the launch stream: nothing to wait for
-            _direct.allreduce_sum_(flat)
-            return None
-        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-    return None
+    """Start the in-place sum over the replicas: it waits for what the current stream has enqueued so far and runs on the exchange
+    stream beside whatever is enqueued next (the remaining backward pass).  Returns a handle for wait_(); None on one replica."""
+    if not active():
+        return None
+    if _direct is not None:
+        return _on_xstream(lambda s: _direct.allreduce_sum_(flat, stream=s))
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
 
 def wait_(work):
-    """make the CURRENT stream wait for an asynchronous collective (no host block with the nccl backend)."""
+    """make the CURRENT stream wait for an asynchronous collective (no host block on the RCCL backends)."""
     if work is not None:
         work.wait()
+
+
+def allreduce_sum_(flat):
+    """in-place sum over replicas of a flat gradient buffer, ordered on the current stream."""
+    wait_(allreduce_sum_async_(flat))
+    return flat
 
 
 def allreduce_mean_(flat):
@@ -110,8 +160,9 @@ def allreduce_mean_(flat):
 def broadcast_(flat, src=0):
     if active():
         if _direct is not None:
-            return _direct.broadcast_(flat, src)
-        dist.broadcast(flat, src=src)
+            _on_xstream(lambda s: _direct.broadcast_(flat, src, stream=s)).wait()
+        else:
+            dist.broadcast(flat, src=src)
     return flat
 
 
@@ -119,7 +170,7 @@ def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if active():
         if _direct is not None:
-            _direct.allreduce_max_f64_(t)
+            _on_xstream(lambda s: _direct.allreduce_max_f64_(t, stream=s)).wait()
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -127,18 +178,18 @@ def max_over_ranks(value, device):
 
 def barrier():
     if active():
-        if _direct is not None:                      # a one-element sum every rank must reach, then drain the stream
-            _direct.allreduce_sum_(torch.zeros(1, dtype=torch.float32, device='cuda'))
+        if _direct is not None:                      # a one-element sum every rank must reach, then drain the device
+            allreduce_sum_(torch.zeros(1, dtype=torch.float32, device='cuda'))
             torch.cuda.synchronize()
         else:
             dist.barrier()
 
 
 def shutdown():
-    global _direct, _direct_store
+    global _direct, _direct_store, _xstream
     if _direct is not None:
         torch.cuda.synchronize()
         _direct.destroy()
-        _direct = _direct_store = None
+        _direct = _direct_store = _xstream = None
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -32,7 +32,19 @@ for it in range(3):
     tr.sample_latent()
     tr.train_iteration()
     sums.append([float(st.p.double().sum().item()) for st in tr.cx.stores.values()])
+# data-parallel resume: rank 0 writes, every rank restores — weights are rank 0's, the random streams stay per rank
+from tg import dist as tgdist
+from Training.Saver import Saver
+if rank == 0:
+    sv = Saver({ckpt!r})
+    sv.set_save_path(comments='dp')
+    sv.save(tr, 'model_0001.ckpt')
+tgdist.barrier()
+Saver({ckpt!r}).restore(tr)
+tr.sample_latent()
+torch.cuda.synchronize()
 out = dict(world=tr.world, rank=rank, sums=sums, losses=tr.losses(),
+           z=tr.z_g_ph.t.cpu().numpy(), rng_state=tr.cx.rng.state.cpu().numpy(),
            p={{k: st.p.cpu().numpy() for k, st in tr.cx.stores.items()}})
 torch.save(out, {out!r} % rank)
 torch.distributed.destroy_process_group()
@@ -53,7 +65,8 @@ def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, graph):
     port = _free_port()
     out = str(tmp_path / "r%d.pt")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT, graph=graph, out=out))
+    script.write_text(WORKER.format(root=ROOT, graph=graph, out=out, ckpt=str(tmp_path / 'ckpt')))
+    os.makedirs(str(tmp_path / 'ckpt'))
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
@@ -67,6 +80,9 @@ def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, graph):
     for k in r[0]['p']:
         np.testing.assert_array_equal(r[0]['p'][k], r[1]['p'][k])
     assert r[0]['losses'] != r[1]['losses']                  # ... although each rank trained on its own batch
+    # after the restore: same step counter, each rank's own seed -> different latents (round-1 advisor finding: rank 0's seed on all)
+    assert r[0]['rng_state'][1] == r[1]['rng_state'][1] and r[0]['rng_state'][0] != r[1]['rng_state'][0]
+    assert not np.array_equal(r[0]['z'], r[1]['z'])
 
 
 def test_rccl_is_usable_on_this_box(tmp_path):

@@ -77,7 +77,7 @@ def _patch(monkeypatch, ex):
     monkeypatch.setattr(tgdist, 'init', lambda backend=None: (2, 0, 0))
     monkeypatch.setattr(tgdist, 'active', lambda: True)
     monkeypatch.setattr(tgdist, 'world_size', lambda: 2)
-    monkeypatch.setattr(tgdist, 'quiet_capture_needed', lambda: False)
+    monkeypatch.setattr(tgdist, 'graphs_allowed', lambda: True)
     monkeypatch.setattr(tgdist, 'allreduce_sum_', ex.allreduce_sum_)
     monkeypatch.setattr(tgdist, 'allreduce_sum_async_', ex.allreduce_sum_async_)
     monkeypatch.setattr(tgdist, 'wait_', lambda w: w.wait() if w is not None else None)

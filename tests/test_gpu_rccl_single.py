@@ -1,8 +1,10 @@
 """RCCL code path on the one-GPU dev box: TG_DIST_SINGLE=1 creates a ONE-replica nccl process group and routes every collective of
 the trainer through it (communicator bound to the device, weight broadcast, bucketed gradient exchange with the asynchronous
 all-reduce beside a hipGraph launch, barrier, max-over-ranks).  A one-rank sum is the identity, so the run must be bit-identical
-to the plain single-process run.  The run also widens the hipGraph capture windows to check that no collective is pending on the RCCL
-watchdog while a stream captures (see Train._capture).  (Several ranks cannot share one GPU under RCCL; tests/test_gpu_dp.py covers two ranks with
+to the plain single-process run.  Two transports: the default rccl-direct one (include/tg_comm.h on the exchange stream; hipGraphs
+on, with widened capture windows: nothing may touch an event while the launch stream captures) and torch's process group ('nccl'),
+beside which the trainer must NOT capture (its watchdog thread aborts the process on ROCm when it polls during a capture — round 1,
+tg/dist.py) and launches eagerly.  (Several ranks cannot share one GPU under RCCL; tests/test_gpu_dp.py covers two ranks with
 gloo as the transport.)"""
 import os
 import socket
@@ -35,7 +37,8 @@ tgdist.barrier()
 t = tgdist.max_over_ranks(1.25, tr.cx.device)
 torch.cuda.synchronize()
 backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else ('rccl-direct' if tgdist._direct is not None else None)
-out = dict(active=tgdist.active(), backend=backend, t=t,
+out = dict(active=tgdist.active(), backend=backend, t=t, rccl_ranks=tgdist.rccl_ranks(),
+           graphs=any(g is not None for g in (tr._graphs or {{}}).get('full', [])),
            losses=tr.losses(), p={{k: st.p.cpu().numpy() for k, st in tr.cx.stores.items()}})
 torch.save(out, {out!r})
 tgdist.shutdown()
@@ -47,8 +50,7 @@ def _run(tmp_path, single, backend=None):
     out = str(tmp_path / ('single%s.pt' % (backend or '') if single else 'plain.pt'))
     script = tmp_path / ('w%d%s.py' % (single, backend or ''))
     script.write_text(WORKER.format(root=ROOT, out=out))
-    err = ''
-    for attempt in range(2):              # one retry with a fresh rendezvous port: the process-group start-up is outside what is tested
+    for attempt in range(2):
         s = socket.socket()
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -60,23 +62,28 @@ def _run(tmp_path, single, backend=None):
             env['TG_DIST_BACKEND'] = backend
         if single:
             env['TG_DIST_SINGLE'] = '1'
-            # widen every capture window beyond the RCCL watchdog's polling period: a collective still on the watchdog's list while a
-            # stream captures kills the process on ROCm (hipErrorCapturedEvent) — Train._capture must have drained the list before
+            # widen every capture window: anything that polled a HIP event from another thread while the launch stream captures would
+            # kill the process on ROCm (hipErrorCapturedEvent)
             env['TG_DEBUG_CAPTURE_SLEEP'] = '0.3'
         r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
         if r.returncode == 0:
             return torch.load(out, weights_only=False)
-        err = r.stderr[-3000:]
+        # the only failure that is retried: another process took the probed rendezvous port between the probe and the bind
+        if attempt == 0 and ('EADDRINUSE' in r.stderr or 'ddress already in use' in r.stderr):
+            continue
+        break
+    err = r.stderr[-3000:]
     dbg = os.path.join(ROOT, 'gpurun_out')
     if os.path.isdir(dbg):
         open(os.path.join(dbg, 'rccl_single_stderr.txt'), 'w').write(err)
-    raise AssertionError(err)
+    raise AssertionError("worker exited with %d:\n%s" % (r.returncode, err))
 
 
-def test_one_replica_rccl_run_is_bit_identical(tmp_path):
+def test_one_replica_process_group_run_is_bit_identical_and_eager(tmp_path):
     plain = _run(tmp_path, False)
-    single = _run(tmp_path, True)
-    assert plain['active'] is False and single['active'] is True and single['backend'] == 'nccl'
+    single = _run(tmp_path, True, backend='nccl')
+    assert plain['active'] is False and plain['graphs'] is True
+    assert single['active'] is True and single['backend'] == 'nccl' and single['graphs'] is False
     assert single['t'] == 1.25
     assert single['losses'] == plain['losses']
     for k in plain['p']:
@@ -84,10 +91,10 @@ def test_one_replica_rccl_run_is_bit_identical(tmp_path):
 
 
 def test_one_replica_direct_rccl_run_is_bit_identical(tmp_path):
-    """the same run with TG_DIST_BACKEND=rccl-direct: every collective is a tg_comm.h call (libtg_comm.so) on the launch stream."""
+    """the default transport: every collective is a tg_comm.h call (libtg_comm.so) on the exchange stream, graphs captured."""
     plain = _run(tmp_path, False)
-    single = _run(tmp_path, True, backend='rccl-direct')
-    assert single['active'] is True and single['backend'] == 'rccl-direct'
+    single = _run(tmp_path, True)
+    assert single['active'] is True and single['backend'] == 'rccl-direct' and single['graphs'] is True and single['rccl_ranks'] == 1
     assert single['t'] == 1.25
     assert single['losses'] == plain['losses']
     for k in plain['p']:

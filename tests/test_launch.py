@@ -1,0 +1,124 @@
+"""`bench.py --gpus N` starts its own ranks (tg/launch.py) — exercised on the CPU with gloo as the transport, world_size 2:
+the job's single JSON line comes from rank 0 and reports N replicas; a failing rank fails the job; without N devices the bench
+refuses instead of printing a one-GPU figure; the communicator-id rendezvous of the rccl-direct backend (tg/comm.py:exchange_id)
+hands every rank the same bytes, both when rank 0 serves the store and under a launcher's agent store."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "tensorflow-implementation-of-triple-gan_amd")
+
+PARENT = r'''
+import sys
+sys.path.insert(0, {pkg!r})
+from tg import launch
+sys.exit(launch.spawn_ranks({n}, [{script!r}], need_devices=False))
+'''
+
+WORKER = r'''
+import json, os, sys, time
+sys.path.insert(0, {pkg!r})
+import torch
+from tg import dist as tgdist
+mode = {mode!r}
+rank = int(os.environ['RANK'])
+if mode == 'fail' and rank == 1:
+    sys.exit(3)
+world, rank, local = tgdist.init(backend='gloo')
+t = torch.full((4,), float(rank + 1))
+tgdist.allreduce_sum_(t)
+slow = tgdist.max_over_ranks(1.0 + rank, torch.device('cpu'))
+tgdist.barrier()
+if mode == 'fail':
+    time.sleep(120)                       # never reached by a healthy job: the launcher stops this rank when rank 1 fails
+if rank == 0:
+    print(json.dumps(dict(n_gpus=world, ranks=tgdist.rccl_ranks(), backend=tgdist.backend_name(), sum=t.tolist(), slow=slow,
+                          spawned=os.environ.get('TG_SPAWNED'))), flush=True)
+else:
+    print("rank 1 must stay silent on stdout", flush=True)
+tgdist.shutdown()
+'''
+
+
+def _job(tmp_path, mode, n=2):
+    w = tmp_path / 'worker.py'
+    w.write_text(WORKER.format(pkg=PKG, mode=mode))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'TG_DIST_BACKEND')}
+    return subprocess.run([sys.executable, '-c', PARENT.format(pkg=PKG, n=n, script=str(w))], env=env, capture_output=True, text=True,
+                          timeout=300)
+
+
+def test_spawned_ranks_report_one_line_from_rank_zero(tmp_path):
+    r = _job(tmp_path, 'ok')
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith('[Gloo]')]       # gloo's own connection notice
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == dict(n_gpus=2, ranks=2, backend='gloo', sum=[3.0] * 4, slow=2.0, spawned='1')
+
+
+def test_a_failing_rank_fails_the_job_and_stops_the_others(tmp_path):
+    t0 = time.time()
+    r = _job(tmp_path, 'fail')
+    assert r.returncode == 3 and '{' not in r.stdout, (r.returncode, r.stdout, r.stderr[-1000:])
+    assert time.time() - t0 < 90          # rank 0 was terminated, not waited for
+
+
+def test_bench_refuses_more_replicas_than_devices():
+    """no GPU in the build container: --gpus 2 must exit non-zero and print no JSON line (round 1 printed n_gpus = 1)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this box could run two replicas")
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip() and 'HIP device' in r.stderr
+    # and a world that disagrees with --gpus is an error as well, also for WORLD_SIZE=1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=dict(env, WORLD_SIZE='1', RANK='0'),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip() and 'WORLD_SIZE=1' in r.stderr
+
+
+ID_WORKER = r'''
+import os, sys
+sys.path.insert(0, {pkg!r})
+from tg import comm
+world, rank = int(os.environ['WORLD_SIZE']), int(os.environ['RANK'])
+uid, store = comm.exchange_id(world, rank, lambda: bytes(range(128)) if rank == 0 else b'never')
+assert uid == bytes(range(128)), uid
+if rank == 0:
+    print('id ok', flush=True)
+'''
+
+
+def test_communicator_id_rendezvous(tmp_path):
+    w = tmp_path / 'idw.py'
+    w.write_text(ID_WORKER.format(pkg=PKG))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'TORCHELASTIC_USE_AGENT_STORE')}
+    r = subprocess.run([sys.executable, '-c', PARENT.format(pkg=PKG, n=2, script=str(w))], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == 'id ok', (r.stdout, r.stderr[-2000:])
+
+
+def test_communicator_id_rendezvous_under_an_agent_store(tmp_path):
+    """torchrun's elastic agent already listens on MASTER_PORT (TORCHELASTIC_USE_AGENT_STORE=True): every rank connects as a client."""
+    import datetime
+    import torch.distributed as dist
+    sys.path.insert(0, PKG)
+    from tg import launch
+    port = launch.free_port()
+    agent = dist.TCPStore('127.0.0.1', port, None, is_master=True, timeout=datetime.timedelta(seconds=60), wait_for_workers=False)
+    w = tmp_path / 'idw.py'
+    w.write_text(ID_WORKER.format(pkg=PKG))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   TORCHELASTIC_USE_AGENT_STORE='True', TORCHELASTIC_RUN_ID='job7')
+        procs.append(subprocess.Popen([sys.executable, str(w)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert outs[0][0].strip() == 'id ok'
+    del agent

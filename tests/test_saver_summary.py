@@ -127,3 +127,32 @@ def test_summary_writes_tensorboard_event_files(tmp_path):
     assert [e['step'] for e in events[1:]] == [1, 2]
     assert events[1]['scalars'] == {'g_loss': 0.5, 'd_loss': 1.25} and events[2]['scalars'] == {'g_loss': 0.25, 'd_loss': 1.0}
     assert open(os.path.join(s.log_dir, 'history.csv')).read().splitlines() == ['step,g_loss,d_loss', '1,0.5,1.25', '2,0.25,1']
+
+
+def test_replica_resume_keeps_each_ranks_seed(tmp_path):
+    """Data-parallel resume (round-1 advisor finding): rank 0 writes the checkpoint, its tg/rng_state holds rank 0's Philox seed.  A
+    replica restoring it takes the step counter only — with rank 0's seed every replica would draw identical latents, dropout
+    masks and noise.  A single-process resume still restores the full state (bit-identical continuation, tests/test_gpu_resume.py)."""
+    from Training.Saver import Saver
+    writer = fake_session(1)
+    writer.cx.rng.state.copy_(torch.tensor([11, 42], dtype=torch.int64))            # rank 0: seed 11, 42 iterations done
+    saver = Saver(str(tmp_path))
+    saver.set_save_path(comments='dp')
+    saver.save(writer, 'model_0001.ckpt')
+    ranks = []
+    for rank in range(2):
+        s = fake_session(5 + rank)
+        s.world, s.rank = 2, rank
+        s.cx.rng.state.copy_(torch.tensor([11 + 7919 * rank, 0], dtype=torch.int64))   # Train.__init__: SEED + 7919 * rank
+        assert Saver(str(tmp_path)).restore(s) == 1
+        ranks.append(s)
+    assert ranks[0].cx.rng.state.tolist() == [11, 42] and ranks[1].cx.rng.state.tolist() == [11 + 7919, 42]
+    for net in writer.cx.stores:                                                    # weights and slots are the writer's on both ranks
+        for r in ranks:
+            for nm in writer.cx.stores[net].names(True):
+                for which in ('value', 'm', 'v'):
+                    np.testing.assert_array_equal(r.cx.stores[net].get(nm, which), writer.cx.stores[net].get(nm, which))
+    solo = fake_session(9)
+    solo.world = 1
+    Saver(str(tmp_path)).restore(solo)
+    assert solo.cx.rng.state.tolist() == [11, 42]

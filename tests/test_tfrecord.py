@@ -130,6 +130,12 @@ def test_corruption_truncation_and_empty(tmp_path):
         r.gather([0, 3])
     with pytest.raises(TgError, match="out of range"):
         r.gather([4])
+    # crafted geometry in record 0: height * width wraps to 0 in 64 bits (must be rejected, not divided by), or exceeds the image
+    for hh, ww in ((1 << 32, 1 << 32), (1 << 40, 1), (4, 5), (0, 4), (1 << 16, 1 << 16)):
+        q = tmp_path / 'geom.tfrecords'
+        q.write_bytes(O.frame(O.encode_example({'image': bytes(12), 'label': 1, 'height': hh, 'width': ww})))
+        with pytest.raises(TgError, match="image bytes do not match height\\*width"):
+            io.RecordFile(q)
 
 
 def test_shuffle_repeat_batch_streams():
