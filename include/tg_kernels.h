@@ -131,6 +131,44 @@ int tg_igemm_colsum_bf16(const tg_igemm_desc* d, const float* in, const float* w
                          double* colsum, int colsum_zeroed, void* stream);
 int tg_wgrad_bf16(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream);
 
+/* ---- descriptor builders and workspace sizes (host code, no device work) -------------------------------------------------------
+ * Every conv-like op of the hot path as tg_igemm_desc(s), with TensorFlow's padding arithmetic (SAME: out = ceil(in/s), total =
+ * max((out-1)*s + k - in, 0), before = total/2, the extra pixel after; VALID: none) — so that a host binding carries no geometry code
+ * of its own.  Conventions: ld_* = channel strides (multiples of 32 for gathered tensors); ld_out <= 0 means "c_out", n_store < 0 means
+ * "c_out"; pad_same: 1 = 'SAME', 0 = 'VALID'; act / alpha: TG_ACT_* fused after +bias.  Filter layouts the descriptors expect:
+ *   conv2d fwd      OTI   [c_out][k*k][ld_in]        (tg_filter_prep_f32: dst_tr with tr_sb = k*k*ld_in, tr_st = ld_in)
+ *   conv2d dgrad    HWIO  [k*k][c_in_pad][ld_dy]     (dst_same)                       — up to 4 descriptors (input parities of a stride-2 conv)
+ *   deconv fwd      [25][c_out_pad][ld_in] (dst_same of the [kh,kw,Cout,Cin] filter)  — 4 descriptors (output parities), or the merged form
+ *   deconv dgrad    [25][c_in_pad][ld_dy] (dst_tr, per-tap transpose)
+ * The *_wgrad descriptors are what tg_wgrad_f32 takes: `in` = the layer input (conv) or dy (transposed conv), `dout` = dy (conv) or the
+ * layer input (transposed conv). */
+int tg_conv2d_desc_fwd(int n, int h, int w, int ld_in, int c_out, int k, int stride, int pad_same, int ld_out, int n_store, int act, float alpha,
+                       tg_igemm_desc* d);
+int tg_conv2d_desc_dgrad(int n, int h, int w, int c_in_pad, int ld_dy, int k, int stride, int pad_same, int ld_out, int n_store, tg_igemm_desc* descs,
+                         int32_t* n_desc_out);
+int tg_conv2d_desc_wgrad(int n, int h, int w, int ld_in, int c_out_pad, int k, int stride, int pad_same, int ld_dy, tg_igemm_desc* d);
+/* tf.layers.conv2d_transpose 5x5, stride 2, 'same' on [n,h,w,ld_in] -> [n,2h,2w,.] (Model/modle_base.py:246-259) */
+int tg_deconv5x5s2_desc_fwd(int n, int h, int w, int ld_in, int c_out_pad, int ld_out, int n_store, int act, tg_igemm_desc* descs, int32_t* n_desc_out);
+/* the same transposed conv as ONE 3x3 problem whose GEMM columns are (output parity, channel) (tg_igemm_desc.n_group; filter from
+ * tg_deconv_merge_prep_f32 with the returned tapmap[36]): pays for narrow outputs (the 3-channel image layer). */
+int tg_deconv5x5s2_desc_fwd_merged(int n, int h, int w, int ld_in, int c_out, int ld_out, int n_store, int act, tg_igemm_desc* d, int32_t* n_group_out,
+                                   int32_t* tapmap);
+int tg_deconv5x5s2_desc_dgrad(int n, int h, int w, int c_in_pad, int ld_dy, int ld_out, int n_store, tg_igemm_desc* d);
+int tg_deconv5x5s2_desc_wgrad(int n, int h, int w, int ld_dy, int c_in_pad, int ld_x, tg_igemm_desc* d);
+/* y[m, c_out] = x[m, ld_in] @ Wt[c_out][w_sn]^T (w_sn <= 0: ld_in); and the same product with the reduction cut into `splits` (<= 4)
+ * sub-problems of one tg_igemm_multi_f32 launch writing part[m][s][n_out] (finish with tg_splitk_reduce_f32). */
+int tg_dense_desc(int m, int ld_in, int c_out, int ld_out, int n_store, int act, int64_t w_sn, tg_igemm_desc* d);
+int tg_dense_splitk_desc(int m, int k_dim, int n_out, int splits, tg_igemm_desc* descs);
+/* pixel splits tg_wgrad_f32 should be given for descriptor d (fills one round of the resident workgroups; >= 1, < 0 on error) and the
+ * bytes of its slab for n_split; bytes of one prepared filter layout [n_taps][c_in_pad][c_out_pad]. */
+int tg_wgrad_splits(const tg_igemm_desc* d);
+int64_t tg_wgrad_workspace_bytes(const tg_igemm_desc* d, int n_split);
+int64_t tg_filter_workspace_bytes(int n_taps, int c_in_pad, int c_out_pad);
+/* the workgroup tile (rows x columns) the launcher picks for these sub-problems (nseg > 0: the tg_igemm_colsum_* constraint that a
+ * tile straddles at most one segment boundary), and whether tg_igemm_colsum_f32 / tg_igemm_actsum_f32 accept (d, seg_rows): 1 / 0. */
+int tg_igemm_tile(const tg_igemm_desc* descs, int n_desc, const int32_t* seg_rows, int nseg, int bf16, int32_t* bm_out, int32_t* bn_out);
+int tg_igemm_colsum_supported(const tg_igemm_desc* d, const int32_t* seg_rows, int nseg);
+
 /* ---- parameter-side kernels ---------------------------------------------------------------------- */
 /* scale[c] = g[c] * rsqrt(max(sum_r V[r][c]^2, 1e-12)), V row-major [rows][c].
  * tf.nn.l2_normalize(V,[0,1,2])*g of conv2d_WN (Model/nn.py:502) and g/sqrt(sum V^2) of dense_WN (nn.py:554). */
@@ -275,6 +313,10 @@ int tg_im2col3x3_add_f32(const float* x, const float* add, int n, int h, int w, 
  * (modle_base.py:239-244).  mask may be NULL. */
 int tg_cond_concat_f32(const float* x, int ld_x, int c, const float* mask, int ld_mask, float mscale, const float* y, int ncls, float* out,
                        int ld_out, int n_img, int hw, void* stream);
+/* y[r][:c] = act(x[r][:c]), zero up to ld_y: an activation CALLED on a tensor (tf.nn.relu / leaky_relu / softplus / tanh / sigmoid,
+ * Model/modle_base.py:176-188, Good_GAN_cifar10.py:19-27; tf.nn.sigmoid of the discriminator's logit, :97).  The models fuse their
+ * activations into the producing kernel instead (tg_igemm_desc.act). */
+int tg_act_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int c, int act, float alpha, void* stream);
 /* out[r][:c] = dy[r][:c]*mask*mscale*act'(yact[r][:c]), zero up to ld_out (mask, yact may be NULL). */
 int tg_actgrad_f32(const float* dy, int ld_dy, const float* yact, int ld_y, const float* mask, int ld_mask, float mscale, float* out, int ld_out,
                    int rows, int c, int act, float alpha, void* stream);
@@ -349,6 +391,21 @@ int tg_minibatch_disc_fwd_f32(const float* act, int ld_a, const float* x, int ld
                               int dim, void* stream);
 int tg_minibatch_disc_bwd_f32(const float* act, int ld_a, const float* df, int ld_df, float* dact, int ld_da, float* db, int n, int kernels, int dim,
                               void* stream);
+/* Stand-alone heads behind the reference's Train_base helper methods (value + d/dlogits; dlogits may be NULL; accumulate != 0 adds to
+ * dlogits instead of writing, so a loss assembled from several helper calls sums into one gradient buffer):
+ *   tg_softmax_ce_f32     T = mean_n softmax-CE(labels, logits)                (_softmax_cross_entropy_loss_w_logits, train_base.py:75-79);
+ *                         labels dense [n][k]; loss[2] = {w T, T}
+ *   tg_bce_logits_f32     T = mean over n*c elements of sigmoid-CE(labels, logits) (_sigmoid_cross_entopy_w_logits, :81-84); labels NULL:
+ *                         the constant `label` everywhere (tf.ones_like / tf.zeros_like, :123-128); loss[2] = {w T, T}
+ *   tg_entropy_terms_f32  H = mean_n(lse - sum_k p_k l_k) (_entropy, :43-48), Bal = -sum_k (1/K) log(mean_n p_k + 1e-12) (_balance_entropy,
+ *                         :50-57); loss[3] = {w_h H + w_bal Bal, H, Bal}
+ * k must be 10 (NUM_CLASSES of every config of the reference). */
+int tg_softmax_ce_f32(const float* logits, int ld, const float* labels, int n, int k, float w, float* dlogits, int ld_d, int accumulate, float* loss,
+                      void* stream);
+int tg_bce_logits_f32(const float* logits, int ld, const float* labels, int ld_y, float label, int n, int c, float w, float* dlogits, int ld_d,
+                      int accumulate, float* loss, void* stream);
+int tg_entropy_terms_f32(const float* logits, int ld, int n, int k, float w_h, float w_bal, float* dlogits, int ld_d, int accumulate, float* loss,
+                         void* stream);
 /* counters[0] += #correct, counters[1] += n (tf.metrics.accuracy, Training/Train_goodGAN.py:428-447). */
 int tg_accuracy_count_f32(const float* logits, int ld, const float* labels, int n, int k, float* counters, void* stream);
 

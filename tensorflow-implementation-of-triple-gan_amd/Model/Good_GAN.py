@@ -160,8 +160,15 @@ class Good_GAN(model_base.NN_Base):
         """:356-426 — the generator graph with reuse."""
         return self.good_generator(z, y, reuse=True)
 
-    def discriminator(self, image, y, reuse=False):
-        """:89-206.  Returns (None, logits [N,1])."""
+    def _d_out(self, logits, want_prob):
+        """(tf.nn.sigmoid(logits), logits) (:124,206); no loss differentiates through the sigmoid."""
+        if not want_prob:
+            return None, logits
+        with ctx().no_record():
+            return ops.activation(logits, 'sigmoid'), logits
+
+    def discriminator(self, image, y, reuse=False, want_prob=True):
+        """:89-206.  Returns (sigmoid(logits), logits [N,1]); want_prob=False (extension, the trainer's solver runs): (None, logits)."""
         cx = ctx()
         lre = self._leaky_relu
         with cx.variable_scope('discriminator'):
@@ -170,7 +177,7 @@ class Good_GAN(model_base.NN_Base):
                 for i in range(5):
                     h = self._WN_dense(ops.cond_concat(h, y.t, y.c), (1000, 500, 250, 250, 250)[i], 'd_h%d_wndense0' % i, init=False, activation=lre)
                     h = self._add_noise(h, stddev=0.2)
-                return None, self._WN_dense(ops.cond_concat(h, y.t, y.c), 1, 'd_h5_wndense0', init=False, narrow=True)
+                return self._d_out(self._WN_dense(ops.cond_concat(h, y.t, y.c), 1, 'd_h5_wndense0', init=False, narrow=True), want_prob)
             image = self._drop_out(image, 0.2, True)                                           # :126-165
             h0 = self._WN_conv2d(self._conv_cond_concat(image, y), 32, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h0_wnconv0", activation=lre)
             h0 = self._WN_conv2d(self._conv_cond_concat(h0, y), 32, k_h=3, k_w=3, d_h=2, d_w=2, init=False, name="d_h0_wnconv1", activation=lre)
@@ -184,8 +191,8 @@ class Good_GAN(model_base.NN_Base):
             h3 = ops.global_avgpool_concat(h2, y.t, y.c)                                        # reduce_mean + concat y
             if self.config.MINIBATCH_DIS:                                                      # :159-162 (off in every config of the reference)
                 h3 = self._minibatch_discrimination(h3, 100, concat_input=True)               # f = ...; h3 = tf.concat([h3, f], 1)
-                return None, self._linear_fc(h3, 1, 'd_h3_lin', narrow=True)
-            return None, self._WN_dense(h3, 1, 'd_h3_wndense', narrow=True)
+                return self._d_out(self._linear_fc(h3, 1, 'd_h3_lin', narrow=True), want_prob)
+            return self._d_out(self._WN_dense(h3, 1, 'd_h3_wndense', narrow=True), want_prob)
 
     def classifier(self, image, train_ph, reuse=False, segments=None):
         """:212-350.  Returns (logits [N,10], feature).  `segments` (extension): image counts of the applications batched into
@@ -242,17 +249,18 @@ class Good_GAN(model_base.NN_Base):
         segs = [p.n for p in parts]
         with cx.rng_scoped(cx.phase + '/C'):
             logits, _ = self.classifier(concat_acts(parts), train, segments=segs)
-        offs = np.cumsum([0] + segs)
+        offs = [int(v) for v in np.cumsum([0] + segs)]
         C_real, C_unl, C_unl_d, C_fake = [logits.view_rows(offs[i], offs[i + 1]) for i in range(4)]
         oh_d = Act(ops.argmax_onehot(C_unl_d, k), C_unl_d.n, 1, 1, k, k)
         oh_u = Act(ops.argmax_onehot(C_unl, k), C_unl.n, 1, 1, k, k)
         ximg = concat_acts([self.as_image(a) for a in (x_l_d, x_u_d, G, x_u_c)])
         yall = concat_acts([y_l_d, oh_d, y_g, oh_u])
         with cx.rng_scoped(cx.phase + '/D'):
-            _, dl = self.discriminator(ximg, yall)
+            dp, dl = self.discriminator(ximg, yall)
         n_p = x_l_d.n + x_u_d.n
-        return [G, [None, dl.view_rows(0, n_p), None, dl.view_rows(n_p, n_p + G.n), None, dl.view_rows(n_p + G.n, dl.n)],
-                [C_real, C_unl, C_unl_d, C_fake]]
+        cut = lambda a: [a.view_rows(0, n_p), a.view_rows(n_p, n_p + G.n), a.view_rows(n_p + G.n, a.n)]
+        (p_real, p_fake, p_unl), (l_real, l_fake, l_unl) = cut(dp), cut(dl)
+        return [G, [p_real, l_real, p_fake, l_fake, p_unl, l_unl], [C_real, C_unl, C_unl_d, C_fake]]
 
 
 def _twice(y):

@@ -108,9 +108,17 @@ class Good_GAN_cifar10(model_base.NN_Base):
 
     # ------------------------------------------------------------------ activations
     def leakyReLu(self, x, alpha=0.2, name=None):
-        """relu(x) - alpha*relu(-x) (:19-27); always fused into the producing kernel."""
-        raise NotImplementedError("pass leakyReLu as nonlinearity= / activation=")
+        """relu(x) - alpha*relu(-x) (:19-27).  Called on a tensor it is one elementwise launch; passed as `nonlinearity=` /
+        `activation=` (what the networks below do) it is fused into the producing kernel's epilogue with the default slope."""
+        return self._leakyReLu_impl(x, alpha)
     leakyReLu.tg_act = ('lrelu', 0.2)
+
+    def _leakyReLu_impl(self, x, alpha):
+        return ops.activation(x, 'lrelu', alpha)
+
+    def gaussian_noise_layer(self, input_layer, std):
+        """input_layer + N(0, std) (:29-31)."""
+        return self._add_noise(input_layer, stddev=std)
 
     # ------------------------------------------------------------------ networks
     def good_generator(self, z, y, init=False, reuse=False):
@@ -135,9 +143,10 @@ class Good_GAN_cifar10(model_base.NN_Base):
         """:176-202 — the same graph as good_generator with reuse=True (BN stays in training mode)."""
         return self.good_generator(z, y, reuse=True)
 
-    def discriminator(self, image, y, init=False, reuse=False, getter=None):
-        """:60-99.  image: Act [N,32,32,3]; y: Act [N,10].  Returns (sigmoid(logits) lazily = None, logits Act [N,1]).
-        Dropout 0.2 is ALWAYS active (training=True literal, :63,73,83)."""
+    def discriminator(self, image, y, init=False, reuse=False, getter=None, want_prob=True):
+        """:60-99.  image: Act [N,32,32,3]; y: Act [N,10].  Returns (tf.nn.sigmoid(h3), h3) = (Act [N,1], logits Act [N,1]).
+        Dropout 0.2 is ALWAYS active (training=True literal, :63,73,83).  want_prob=False (extension; the trainer's solver runs, which
+        fetch only the losses): the sigmoid launch is skipped and None returned in its place."""
         cx = ctx()
         lre = self.leakyReLu
         with cx.variable_scope('discriminator'):
@@ -149,7 +158,12 @@ class Good_GAN_cifar10(model_base.NN_Base):
                     h2 = self._drop_out(_dense_view(h2), 0.2, True)
             h3 = ops.global_avgpool_concat(h2, y.t, y.c)                             # avg_pool 8 + squeeze + concat y
             h3 = self._linear_fc(h3, 1, 'lin', narrow=True)
-        return None, h3
+        return (self._sigmoid_no_grad(h3) if want_prob else None), h3
+
+    def _sigmoid_no_grad(self, logits):
+        """tf.nn.sigmoid(logits) as an output: no loss of the reference differentiates through it (they all take the logits)."""
+        with ctx().no_record():
+            return ops.activation(logits, 'sigmoid')
 
     def classifier(self, inp, is_training, init=False, reuse=False, getter=None, segments=None):
         """:101-174.  inp: Act [N,32,32,3] (ZCA-whitened).  Returns (logits Act [N,10], feature Act [N,128]).
@@ -194,8 +208,11 @@ class Good_GAN_cifar10(model_base.NN_Base):
 
     def forward_pass(self, z_g, y_g, x_l_c, y_l_c, x_l_d, y_l_d, x_u_d, x_u_c, train):
         """:204-278.  Executes every application eagerly (the trainer runs per-solver sub-graphs instead,
-        Training/Train_goodGAN.py).  Returns [G, [None, D_real_logits, None, D_fake_logits, None, D_unl_logits],
-        [C_real, C_unl, C_unl_d, C_fake, C_unl_rep]] with logits as Act handles."""
+        Training/Train_goodGAN.py).  Returns [G, [D_real, D_real_logits, D_fake, D_fake_logits, D_unl, D_unl_logits],
+        [C_real_logits, C_unl_logits, C_unl_d_logits, C_fake_logits, C_unl_logits_rep]] as Act handles; the three discriminator
+        applications run as one batched call (no batch statistics in D: identical arithmetic), the five classifier ones as one call
+        with per-application mean-only-BN statistics and pop_mean updates in the reference's call-site order (real, unl, unl_rep, unl_d,
+        fake: :228-240)."""
         from tg.batching import concat_acts
         cx = ctx()
         G = self.good_generator(z_g, y_g)
@@ -204,17 +221,18 @@ class Good_GAN_cifar10(model_base.NN_Base):
         xc = concat_acts([w.apply(x_l_c), w.apply(x_u_c), w.apply(x_u_c), w.apply(x_u_d), w.apply(G)])
         with cx.rng_scoped(cx.phase + '/C'):
             logits, _ = self.classifier(xc, train, segments=segs)
-        offs = np.cumsum([0] + segs)
+        offs = [int(v) for v in np.cumsum([0] + segs)]
         C_real, C_unl, C_rep, C_unl_d, C_fake = [logits.view_rows(offs[i], offs[i + 1]) for i in range(5)]
         oh_d = _onehot_act(C_unl_d, self.config.NUM_CLASSES)
         oh_u = _onehot_act(C_unl, self.config.NUM_CLASSES)
         ximg = concat_acts([x_l_d, x_u_d, G, x_u_c])
         yall = concat_acts([y_l_d, oh_d, y_g, oh_u])
         with cx.rng_scoped(cx.phase + '/D'):
-            _, dl = self.discriminator(ximg, yall)
+            dp, dl = self.discriminator(ximg, yall)
         n_p = x_l_d.n + x_u_d.n
-        return [G, [None, dl.view_rows(0, n_p), None, dl.view_rows(n_p, n_p + G.n), None, dl.view_rows(n_p + G.n, dl.n)],
-                [C_real, C_unl, C_unl_d, C_fake, C_rep]]
+        cut = lambda a: [a.view_rows(0, n_p), a.view_rows(n_p, n_p + G.n), a.view_rows(n_p + G.n, a.n)]
+        (p_real, p_fake, p_unl), (l_real, l_fake, l_unl) = cut(dp), cut(dl)
+        return [G, [p_real, l_real, p_fake, l_fake, p_unl, l_unl], [C_real, C_unl, C_unl_d, C_fake, C_rep]]
 
 
 def _dense_view(a):

@@ -33,26 +33,27 @@ class NN_Base(object):
     def forward_pass(self, x):
         raise NotImplementedError('forward_pass() is implemented in Model sub classes')
 
-    # ---- activations usable as `activation=` / `nonlinearity=` ------------------------------------
+    # ---- activations: callable on a tensor (one elementwise launch, modle_base.py:170-188) AND usable as `activation=` /
+    # `nonlinearity=` of a layer, which fuses them into the producing kernel's epilogue (what the models of this package do)
     def _relu(self, x):
-        raise NotImplementedError("standalone relu is always fused: pass activation=self._relu")
+        return ops.activation(x, 'relu')
     _relu.tg_act = ('relu', 0.0)
 
     def _tanh(self, x):
-        raise NotImplementedError("standalone tanh is always fused: pass activation=self._tanh")
+        return ops.activation(x, 'tanh')
     _tanh.tg_act = ('tanh', 0.0)
 
     def _leaky_relu(self, x, alpha=0.2):
-        """tf.nn.leaky_relu (default alpha 0.2; modle_base.py:181-182) — fused: pass activation=self._leaky_relu."""
-        raise NotImplementedError("standalone leaky_relu is always fused: pass activation=self._leaky_relu")
+        """tf.nn.leaky_relu (modle_base.py:181-182); as `activation=` the slope is the default 0.2."""
+        return ops.activation(x, 'lrelu', alpha)
     _leaky_relu.tg_act = ('lrelu', 0.2)
 
     def _softplus(self, x):
-        raise NotImplementedError("standalone softplus is always fused: pass activation=self._softplus")
+        return ops.activation(x, 'softplus')
     _softplus.tg_act = ('softplus', 0.0)
 
     def _sigmoid(self, x):
-        raise NotImplementedError("standalone sigmoid is always fused: pass activation=self._sigmoid")
+        return ops.activation(x, 'sigmoid')
     _sigmoid.tg_act = ('sigmoid', 0.0)
 
     # ---- layers -----------------------------------------------------------------------------------

@@ -124,7 +124,7 @@ class Train(Train_base):
             ximg = concat_acts([m.as_image(a) for a in (self.x_l_d_ph, self.x_u_d_ph, G, self.x_u_c_ph)])   # X_P | G | x_u_c (:258-271)
             yall = concat_acts([self.y_l_d_ph, oh_unl_d, self.y_g_ph, oh_unl])
             with cx.rng_scoped('D/D'):
-                _, d_logits = m.discriminator(ximg, yall)
+                _, d_logits = m.discriminator(ximg, yall, want_prob=False)
             self._d_loss(d_logits, c.BATCH_SIZE_L_D + c.BATCH_SIZE_U_D, c.BATCH_SIZE_G, c.BATCH_SIZE_U_C, self.loss_dev[0:1])
             cx.backward()
 
@@ -138,7 +138,7 @@ class Train(Train_base):
             else:
                 G, g_tape = m.good_generator(self.z_g_ph, self.y_g_ph), None
             with cx.rng_scoped('G/D'):
-                _, d_fake = m.discriminator(G, self.y_g_ph)
+                _, d_fake = m.discriminator(G, self.y_g_ph, want_prob=False)
             self._g_loss(d_fake, self.loss_dev[1:2])
             cx.backward()
             if g_tape is not None:
@@ -161,7 +161,7 @@ class Train(Train_base):
             k = c.NUM_CLASSES
             oh_unl = Act(ops.argmax_onehot(c_unl, k), c_unl.n, 1, 1, k, k)
             with cx.rng_scoped('C/D'):
-                _, d_unl = m.discriminator(self.x_u_c_ph, oh_unl)
+                _, d_unl = m.discriminator(self.x_u_c_ph, oh_unl, want_prob=False)
             self._c_loss(c_logits, segs[0], segs[1], segs[1] if rep else 0, G.n, self.y_l_c_ph, self.y_g_ph, d_unl,
                          self.hyper[2:4], self.loss_dev[2:3])
             self._c_rest = (cx.backward(stop_at_boundary=split), cx.counter)
@@ -299,11 +299,23 @@ class Train(Train_base):
         return tuple(float(v) for v in self.loss_dev.detach().cpu().numpy())
 
     # ------------------------------------------------------------------ evaluation
+    def _metric(self, real_lab_logits, real_lab, metric=None):
+        """:428-447: streaming accuracy of argmax(real_lab_logits) against argmax(real_lab).  Returns the reference's tuple
+        (accuracy, update_op, reset_op, prediction, probs): accuracy — float(accuracy) reads the running value (this batch already
+        counted); update_op(labels, logits) adds a batch; reset_op() clears the counters; prediction — one-hot arg-max of the logits
+        (device tensor [n,k]); probs — None (the reference's `probs` output is never fetched)."""
+        accuracy, update_op = self._accuracy_metric(real_lab, real_lab_logits, metric)
+        return accuracy, update_op, accuracy.reset, ops.argmax_onehot(real_lab_logits, real_lab_logits.c), None
+
+    def _goodGAN_loss(self, G, D, C, X, Y, Lambda, discriminator=None):
+        """:449-454."""
+        return self._loss_GAN(D, C, Y, Lambda)
+
     def evaluate(self, batches):
         """streaming accuracy of argmax C_real_logits vs argmax y over test batches with train=False (:295-351, :428-447).
         batches: iterable of (x [n,h,w,c], y onehot [n,k]) host arrays.  Returns accuracy."""
-        c, cx, m = self.config, self.cx, self.model
-        counters = torch.zeros(2, dtype=torch.float32, device=cx.device)
+        cx, m = self.cx, self.model
+        metric = None
         for x, y in batches:
             with cx.phase_scope('val', record=False):
                 xa = cx.from_numpy(x, key='val:x')
@@ -312,9 +324,8 @@ class Train(Train_base):
                     xa = m.zca().apply(m.as_image(xa))
                 with cx.rng_scoped('val/C'):
                     logits, _ = m.classifier(xa, False)
-                lib.call('tg_accuracy_count_f32', logits.ptr, logits.ld, ya.ptr, logits.n, c.NUM_CLASSES, lib.ptr(counters), cx.stream)
-        correct, total = counters.cpu().numpy()
-        return float(correct) / max(float(total), 1.0)
+                metric = self._metric(logits, ya, metric)[0]
+        return float(metric) if metric is not None else 0.0
 
     def sync_running_state(self):
         """Replicas keep their own running statistics (pop_mean, batch-norm moving mean / variance) and EMA shadows while

@@ -1,12 +1,43 @@
 """Train_base — loss / optimiser library, counterpart of the reference's Training/train_base.py.
 
-`_loss_GAN` (train_base.py:113-154) is kept as the one loss the entry point calls; it is evaluated by three fused
+`_loss_GAN(D, C, Y, Lambda)` (train_base.py:113-154) is kept as the one loss the entry point calls; it is evaluated by three fused
 single-launch kernels (tg_d_loss_f32 / tg_g_loss_f32 / tg_c_loss_f32) that also write d(loss)/d(logits) into the
-logits' gradient buffers.  `_Adam_optimizer` (:91-97) returns the TF-form Adam configuration applied by
+logits' gradient buffers.  The helper methods it is written with in the reference — `_entropy`, `_balance_entropy` (:43-57),
+`_softmax_cross_entropy_loss_w_logits`, `_sigmoid_cross_entopy_w_logits` (:75-84), `_accuracy_metric` (:107) — keep their names and
+argument order as stand-alone single-launch heads.  `_Adam_optimizer` (:91-97) returns the TF-form Adam configuration applied by
 tg_adam_f32 over a network's flat buffers; `_train_op` applies it.
+
+Eager-mode conventions: a loss value is a 1-element DEVICE tensor (float(t) synchronises); every head also leaves d(value)/d(logits)
+in `logits.grad` — written when the tensor has no gradient yet, ADDED when it has, so a loss summed from several heads accumulates
+its gradient the way TensorFlow's autodiff would; `weight` scales value and gradient.
 """
+import torch
+
 from tg import lib
 from tg.runtime import ctx
+
+
+class StreamingAccuracy(object):
+    """tf.metrics.accuracy (train_base.py:107): device counters {correct, total}; float(metric) = the accuracy so far."""
+
+    def __init__(self, num_classes=10):
+        self.k = num_classes
+        self.counters = torch.zeros(2, dtype=torch.float32, device=ctx().device)
+
+    def update(self, labels, logits):
+        """labels: one-hot Act [n,k]; logits: Act [n,k] — arg-max of both is taken in the kernel."""
+        lib.call('tg_accuracy_count_f32', logits.ptr, logits.ld, labels.ptr, logits.n, self.k, lib.ptr(self.counters), ctx().stream)
+        return self
+
+    def reset(self):
+        lib.call('tg_fill_f32', lib.ptr(self.counters), 0.0, 2, ctx().stream)
+        return self
+
+    def result(self):
+        correct, total = self.counters.cpu().numpy()
+        return float(correct) / max(float(total), 1.0)
+
+    __float__ = result
 
 
 class AdamOptimizer(object):
@@ -30,6 +61,60 @@ class Train_base(object):
 
     def _build_train_graph(self):
         raise NotImplementedError('loss() is implemented in Model sub classes')
+
+    # ---- helper heads (train_base.py:43-57,75-84,107) -----------------------------------------------
+    @staticmethod
+    def _grad_of_logits(logits):
+        """(gradient Act, accumulate flag) — see the module docstring."""
+        cx = ctx()
+        if logits.grad is None:
+            logits.grad = cx.new_act(logits.n, logits.h, logits.w, logits.c, logits.ld, tag='dl')
+            return logits.grad, 0
+        return logits.grad, 1
+
+    def _entropy(self, logits, weight=1.0):
+        """mean_n(logsumexp(l) - sum_k softmax_k l_k) (train_base.py:43-48)."""
+        cx = ctx()
+        out = cx.scratch('lossv', 4)
+        g, acc = self._grad_of_logits(logits)
+        lib.call('tg_entropy_terms_f32', logits.ptr, logits.ld, logits.n, logits.c, float(weight), 0.0, g.ptr, g.ld, acc, lib.ptr(out), cx.stream)
+        return out[0:1]
+
+    def _balance_entropy(self, logits, weight=1.0):
+        """-sum_k (1/K) log(mean_n softmax_k + 1e-12) (train_base.py:50-57)."""
+        cx = ctx()
+        out = cx.scratch('lossv', 4)
+        g, acc = self._grad_of_logits(logits)
+        lib.call('tg_entropy_terms_f32', logits.ptr, logits.ld, logits.n, logits.c, 0.0, float(weight), g.ptr, g.ld, acc, lib.ptr(out), cx.stream)
+        return out[0:1]
+
+    def _softmax_cross_entropy_loss_w_logits(self, labels, logits, weight=1.0):
+        """reduce_mean(softmax_cross_entropy_with_logits_v2(labels, logits)) (train_base.py:75-79); labels: dense Act [n,k]."""
+        cx = ctx()
+        assert labels.ld == labels.c == logits.c and labels.n == logits.n
+        out = cx.scratch('lossv', 4)
+        g, acc = self._grad_of_logits(logits)
+        lib.call('tg_softmax_ce_f32', logits.ptr, logits.ld, labels.ptr, logits.n, logits.c, float(weight), g.ptr, g.ld, acc, lib.ptr(out), cx.stream)
+        return out[0:1]
+
+    def _sigmoid_cross_entopy_w_logits(self, labels, logits, weight=1.0):
+        """reduce_mean(sigmoid_cross_entropy_with_logits(labels, logits)) (train_base.py:81-84).  labels: an Act of the logits' shape, or a
+        number standing for tf.ones_like(logits) / tf.zeros_like(logits) (:123-128)."""
+        cx = ctx()
+        out = cx.scratch('lossv', 4)
+        g, acc = self._grad_of_logits(logits)
+        const = not hasattr(labels, 'ptr')
+        lib.call('tg_bce_logits_f32', logits.ptr, logits.ld, None if const else labels.ptr, 0 if const else labels.ld, float(labels) if const else 0.0,
+                 logits.rows, logits.c, float(weight), g.ptr, g.ld, acc, lib.ptr(out), cx.stream)
+        return out[0:1]
+
+    def _accuracy_metric(self, labels, predictions, metric=None):
+        """tf.metrics.accuracy(labels, predictions) (train_base.py:107) -> (accuracy, update_op): one update with this batch on `metric`
+        (a new StreamingAccuracy when None); float(accuracy) reads the running value, update_op(labels, predictions) adds a batch.
+        labels: one-hot Act; predictions: logits Act (the arg-max of Train._metric, Train_goodGAN.py:432-433, happens in the kernel)."""
+        metric = metric if metric is not None else StreamingAccuracy(predictions.c)
+        metric.update(labels, predictions)
+        return metric, metric.update
 
     def _Adam_optimizer(self, lr, beta1, name='Adam_optimizer'):
         return AdamOptimizer(lr, beta1, name=name)
@@ -62,21 +147,31 @@ class Train_base(object):
                  d_unl_logits.ptr, d_unl_logits.ld, lib.ptr(lambdas_dev), g.ptr, g.ld, lib.ptr(loss_out), cx.stream)
         c_logits.grad = g
 
-    def _loss_GAN(self, D, C, Y, Lambda, loss_out):
-        """All three losses of train_base.py:113-154 on the outputs of Model.forward_pass (evaluation / tests).
-        D = [_, D_real_logits, _, D_fake_logits, _, D_unl_logits]; C = [C_real, C_unl, C_unl_d, C_fake(, C_unl_rep)];
-        Y = [y_g, y_l_c]; Lambda = device tensor {lambda_1, lambda_2}; loss_out = device tensor of 3 floats."""
+    def _loss_GAN(self, D, C, Y, Lambda):
+        """train_base.py:113-154 on the outputs of Model.forward_pass, the reference's arguments:
+        D = [D_real, D_real_logits, D_fake, D_fake_logits, D_unl, D_unl_logits]; C = [C_real_logits, C_unl_logits, C_unl_d_logits,
+        C_fake_logits(, C_unl_logits_rep — config.DATA_NAME 'cifar10')]; Y = [y_g, y_l_c]; Lambda = [lambda_1(, lambda_2)] as numbers or
+        a device tensor.  Returns (d_loss, g_loss, c_loss), 1-element device tensors."""
         from tg.batching import concat_acts
+        cx = ctx()
+        loss_out = cx.scratch('loss_gan', 4)
+        if isinstance(Lambda, torch.Tensor):
+            lam = Lambda
+        else:
+            vals = [float(v) for v in Lambda] + [0.0, 0.0]
+            lam = cx.scratch('loss_lambda', 2)
+            lam.copy_(torch.tensor(vals[:2], dtype=torch.float32))
         _, d_real, _, d_fake, _, d_unl = D
         dcat = concat_acts([d_real, d_fake, d_unl])
         self._d_loss(dcat, d_real.n, d_fake.n, d_unl.n, loss_out[0:1])
         self._g_loss(d_fake, loss_out[1:2])
-        c_real, c_unl, _, c_fake = C[:4]
+        c_real, c_unl, _c_unl_d, c_fake = C[:4]
         c_rep = C[4] if len(C) > 4 else None
         ccat = concat_acts([c_real, c_unl] + ([c_rep] if c_rep is not None else []) + [c_fake])
         y_g, y_l_c = Y
-        self._c_loss(ccat, c_real.n, c_unl.n, c_rep.n if c_rep is not None else 0, c_fake.n, y_l_c, y_g, d_unl, Lambda, loss_out[2:3])
-        return loss_out
+        self._c_loss(ccat, c_real.n, c_unl.n, c_rep.n if c_rep is not None else 0, c_fake.n, y_l_c, y_g, d_unl, lam, loss_out[2:3])
+        self.last_loss_inputs = (dcat, ccat)                   # the concatenated logits that carry d(loss)/d(logits)
+        return loss_out[0:1], loss_out[1:2], loss_out[2:3]
 
     # ---- loss variants of train_base.py:156-574 (SURVEY §8f N4) -----------------------------------------------------------------
     # No trainer of the reference repository calls these (Train_goodGAN.py uses _loss_GAN); they are kept for the sibling trainers'

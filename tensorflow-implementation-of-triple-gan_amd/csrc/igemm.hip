@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include "tg_common.h"
 #include "tg_device.h"
+#include "tg_geom.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -757,54 +758,10 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
            bf16 ? " bf16" : "");
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_IGEMM, flops, bytes, s, desc);
-  // tile choice: the largest tile that still gives >= ~1.5 workgroups per CU (2 are resident); small problems (generator,
-  // discriminator tail, ZCA) fall back to 64-row / 64-column tiles for parallelism.
-  // tile choice by a quantisation cost model: every CU is matrix-pipe bound whatever number of tiles is co-resident, so
-  // time ~ ceil(tiles / 256 CUs) * tile area / efficiency.  520 tiles of 128x128 cost 3 tile-times per CU, the same
-  // problem in 64x64 tiles costs ceil(2080/256) = 9 quarter-size ones.  eff: measured on the classifier layers (N = 250).
-  struct Cand { int bm, bn; double eff; };
-  static Cand cands[] = {{128, 128, 1.00}, {64, 128, 0.97}, {64, 64, 1.02}, {128, 64, 0.95}, {32, 128, 0.85}, {128, 32, 0.70}};
-  static bool eff_env = false;
-  // 64x64 at 1.02: with up to four co-resident workgroups per compute unit their prologues / epilogues interleave, whereas the two
-  // 128x128 ones run in lockstep (workgroup timeline: both start and end within 0.2 us) and expose theirs — measured on the bench line
-  // 0.96 -> 1.02: +0.6 % (the 32x32 128-channel layers move to 64x64 tiles); 1.06 / 1.12 bring nothing more.
-  if (!eff_env) {                                         // tuning aid: TG_IGEMM_EFF64 overrides the 64x64 entry
-    eff_env = true;
-    if (const char* e = getenv("TG_IGEMM_EFF64")) cands[2].eff = atof(e);
-  }
-  int bm = 128, bn = 32;
-  double best = 1e300;
-  const char* force = getenv("TG_IGEMM_TILE");     // "bm,bn" — tuning aid
-  int fbm = 0, fbn = 0;
-  if (force) sscanf(force, "%d,%d", &fbm, &fbn);
-  int max_taps = 0;
-  for (int i = 0; i < n_desc; ++i) max_taps = descs[i].n_taps > max_taps ? descs[i].n_taps : max_taps;
-  for (const Cand& c : cands) {
-    // a tile may overhang the last columns (c_out = 544 = 8.5 x 64: nine 64-column tiles instead of seventeen 32-column ones); the
-    // quantisation below charges the idle columns
-    if (d->c_out % c.bn && c.bn > d->c_out) continue;
-    if (force && (c.bm != fbm || c.bn != fbn)) continue;
-    bool seg_ok = true;                                      // COLSUM: a tile may straddle at most one application boundary
-    for (int i = 0; colsum && i < nseg; ++i) seg_ok = seg_ok && seg_rows[i] >= c.bm;
-    if (!seg_ok) continue;
-    const int64_t per_sub = (int64_t)((p.M + c.bm - 1) / c.bm) * ((d->c_out + c.bn - 1) / c.bn);
-    // K-tiles per CU: whole rounds for one problem; for the unequal sub-problems of a stride-2 launch (4/6/6/9 taps of a 5x5
-    // transposed conv) the longest workgroup bounds the launch from below, which is what pushes those to small tiles
-    double iters;
-    if (n_desc == 1) {
-      iters = (double)((per_sub + 255) / 256) * max_taps;
-    } else {
-      // the sub-problems are mixed over the compute units (rotating order, see the kernel): a unit's load is the mean plus about half
-      // of the longest workgroup — measured on the generator's layers: 64x64 tiles 0.124 ms, 64x128 0.153 ms, equal mean load
-      const double total = (double)per_sub * taps / 256.0 + 0.5 * max_taps;
-      iters = total > max_taps ? total : max_taps;
-    }
-    // bf16 operands: the conversion work per tile favours the large tile (measured: CIFAR-10 bf16 step 8.06 ms with 0.96, 8.55 ms with 1.02)
-    const double eff = (bf16 && c.bm == 64 && c.bn == 64 && !getenv("TG_IGEMM_EFF64")) ? 0.96 : c.eff;
-    const double t = iters * c.bm * c.bn / eff;
-    if (t < best) { best = t; bm = c.bm; bn = c.bn; }
-  }
-  TG_REQUIRE(best < 1e299, "igemm: no tile fits c_out=%d with the given segments", d->c_out);
+  // tile choice by the quantisation cost model of geom.cpp (tg::igemm_pick_tile; also behind tg_igemm_tile / tg_igemm_colsum_supported)
+  int bm = 0, bn = 0;
+  TG_REQUIRE(tg::igemm_pick_tile(descs, n_desc, colsum != nullptr, seg_rows, nseg, bf16, &bm, &bn), "igemm: no tile fits c_out=%d with the given segments",
+             d->c_out);
   if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2>(p, s, bf16);
   else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2>(p, s, bf16);
   else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2>(p, s, bf16);
@@ -912,10 +869,8 @@ static int wgrad_impl(const tg_igemm_desc* d, const float* in, const float* dout
            bf16 ? " bf16" : "");
   tg::ProfScope prof(tg::PC_WGRAD, flops, bytes, tg::as_stream(stream), desc);
   hipStream_t s = tg::as_stream(stream);
-  // widest tile that divides the dimension; odd multiples of 32 from 160 on (288 = 256 + 32 label channels, 544, 160) take 64-wide
-  // tiles with an overhanging last one instead of 32-wide ones (tg/ops.py:wgrad_splits mirrors this)
-  auto pick = [](int n) { return n % 128 == 0 ? 128 : ((n % 64 == 0 || n >= 160) ? 64 : 32); };
-  const int ct = pick(d->ld_in), nt = pick(d->c_out);
+  // channel tiles: tg::wgrad_tile (geom.cpp; tg_wgrad_splits sizes the pixel split with the same rule)
+  const int ct = tg::wgrad_tile(d->ld_in), nt = tg::wgrad_tile(d->c_out);
   if (ct == 128 && nt == 128) launch_wgrad<128, 128, 2, 2, 1>(p, s, bf16);
   else if (ct == 128 && nt == 64) launch_wgrad<128, 64, 2, 2, 1>(p, s, bf16);
   else if (ct == 128 && nt == 32) launch_wgrad<128, 32, 4, 1, 1>(p, s, bf16);

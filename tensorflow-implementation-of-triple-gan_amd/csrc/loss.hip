@@ -307,6 +307,97 @@ __global__ void __launch_bounds__(256) pull_away_kernel(const float* __restrict_
   if (threadIdx.x == 0) loss[0] = acc;
 }
 
+// Stand-alone heads behind the reference's Train_base helper methods (train_base.py:43-57,75-84): each is value + d/dlogits, the
+// gradient written or (acc != 0) added so that a loss assembled from several helper calls accumulates into one gradient buffer.
+// mean_n softmax-CE(labels, logits)  (tf.nn.softmax_cross_entropy_with_logits_v2 + reduce_mean); loss = {w T, T}
+__global__ void __launch_bounds__(256) softmax_ce_kernel(const float* __restrict__ z, int ld, const float* __restrict__ y, int n, float w,
+                                                         float* __restrict__ dz, int ld_d, int acc, float* __restrict__ loss) {
+  __shared__ float red[4];
+  float l[KC], p[KC], lse, t = 0.f;
+  for (int r = threadIdx.x; r < n; r += 256) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k) l[k] = z[(int64_t)r * ld + k];
+    softmax10(l, p, &lse);
+    float ysum = 0.f, yl = 0.f;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { const float tt = y[r * KC + k]; ysum += tt; yl += tt * l[k]; }
+    t += (lse * ysum - yl) / n;
+    if (dz) {
+      float* o = dz + (int64_t)r * ld_d;
+#pragma unroll
+      for (int k = 0; k < KC; ++k) o[k] = (acc ? o[k] : 0.f) + w * (p[k] * ysum - y[r * KC + k]) / n;
+      if (!acc) for (int k = KC; k < ld_d; ++k) o[k] = 0.f;
+    }
+  }
+  t = block_sum(t, red);
+  if (threadIdx.x == 0) { loss[0] = w * t; loss[1] = t; }
+}
+
+// mean over n*c elements of sigmoid-CE(labels, logits)  (tf.nn.sigmoid_cross_entropy_with_logits + reduce_mean); labels NULL: the
+// constant `label` everywhere (tf.ones_like / tf.zeros_like, train_base.py:123-128); loss = {w T, T}
+__global__ void __launch_bounds__(256) bce_logits_kernel(const float* __restrict__ z, int ld, const float* __restrict__ y, int ld_y, float label, int n,
+                                                         int c, float w, float* __restrict__ dz, int ld_d, int acc, float* __restrict__ loss) {
+  __shared__ float red[4];
+  float t = 0.f;
+  const float inv = 1.f / ((float)n * c);
+  for (int i = threadIdx.x; i < n * c; i += 256) {
+    const int r = i / c, k = i - r * c;
+    const float v = z[(int64_t)r * ld + k], tt = y ? y[(int64_t)r * ld_y + k] : label;
+    t += bce(v, tt) * inv;
+    if (dz) { float* o = dz + (int64_t)r * ld_d + k; *o = (acc ? *o : 0.f) + w * (sigm(v) - tt) * inv; }
+  }
+  if (dz && !acc && ld_d > c)
+    for (int i = threadIdx.x; i < n * (ld_d - c); i += 256) dz[(int64_t)(i / (ld_d - c)) * ld_d + c + i % (ld_d - c)] = 0.f;
+  t = block_sum(t, red);
+  if (threadIdx.x == 0) { loss[0] = w * t; loss[1] = t; }
+}
+
+// H = mean_n(lse - sum_k p_k l_k) (Train_base._entropy, train_base.py:43-48) and Bal = -sum_k (1/K) log(mean_n p_k + 1e-12)
+// (_balance_entropy, :50-57); loss = {w_h H + w_bal Bal, H, Bal}
+__global__ void __launch_bounds__(256) entropy_terms_kernel(const float* __restrict__ z, int ld, int n, float w_h, float w_bal, float* __restrict__ dz,
+                                                            int ld_d, int acc, float* __restrict__ loss) {
+  __shared__ float red[4];
+  __shared__ float q[KC];
+  float l[KC], p[KC], lse, qa[KC];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) qa[k] = 0.f;
+  for (int r = threadIdx.x; r < n; r += 256) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k) l[k] = z[(int64_t)r * ld + k];
+    softmax10(l, p, &lse);
+#pragma unroll
+    for (int k = 0; k < KC; ++k) qa[k] += p[k];
+  }
+  for (int k = 0; k < KC; ++k) {
+    const float s = block_sum(qa[k], red);
+    if (threadIdx.x == 0) q[k] = s / n;
+  }
+  __syncthreads();
+  float t_h = 0.f;
+  for (int r = threadIdx.x; r < n; r += 256) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k) l[k] = z[(int64_t)r * ld + k];
+    softmax10(l, p, &lse);
+    float pl = 0.f, pdq = 0.f, dq[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { pl += p[k] * l[k]; dq[k] = -1.f / (KC * (q[k] + 1e-12f)) / n; pdq += p[k] * dq[k]; }
+    t_h += (lse - pl) / n;
+    if (dz) {
+      float* o = dz + (int64_t)r * ld_d;
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+        o[k] = (acc ? o[k] : 0.f) + w_h * (p[k] - p[k] * (1.f + l[k] - pl)) / n + w_bal * p[k] * (dq[k] - pdq);
+      if (!acc) for (int k = KC; k < ld_d; ++k) o[k] = 0.f;
+    }
+  }
+  t_h = block_sum(t_h, red);
+  if (threadIdx.x == 0) {
+    float bal = 0.f;
+    for (int k = 0; k < KC; ++k) bal -= logf(q[k] + 1e-12f) / KC;
+    loss[0] = w_h * t_h + w_bal * bal; loss[1] = t_h; loss[2] = bal;
+  }
+}
+
 // counters[0] += #(argmax logits == argmax labels), counters[1] += n     (tf.metrics.accuracy, Train_goodGAN.py:428-447)
 __global__ void __launch_bounds__(256) accuracy_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ labels, int n, int k,
                                                        float* __restrict__ counters) {
@@ -397,6 +488,24 @@ int tg_feature_match_f32(const float* f_fake, int n_fake, const float* f_unl, in
 int tg_pull_away_f32(const float* f, int n, int c, int masked, float* scratch, float* df, float* loss, void* stream) {
   TG_REQUIRE(f && scratch && df && loss && n > 1 && c > 0, "pull_away: bad args");
   LOSS_LAUNCH(pull_away_kernel, f, n, c, masked, scratch, df, loss)
+}
+
+int tg_softmax_ce_f32(const float* logits, int ld, const float* labels, int n, int k, float w, float* dlogits, int ld_d, int accumulate, float* loss,
+                      void* stream) {
+  TG_REQUIRE(logits && labels && loss && n > 0 && k == KC && ld >= KC && (!dlogits || ld_d >= KC), "softmax_ce: bad args (k must be %d)", KC);
+  LOSS_LAUNCH(softmax_ce_kernel, logits, ld, labels, n, w, dlogits, ld_d, accumulate, loss)
+}
+
+int tg_bce_logits_f32(const float* logits, int ld, const float* labels, int ld_y, float label, int n, int c, float w, float* dlogits, int ld_d,
+                      int accumulate, float* loss, void* stream) {
+  TG_REQUIRE(logits && loss && n > 0 && c > 0 && c <= ld && (!labels || c <= ld_y) && (!dlogits || c <= ld_d), "bce_logits: bad args");
+  LOSS_LAUNCH(bce_logits_kernel, logits, ld, labels, ld_y, label, n, c, w, dlogits, ld_d, accumulate, loss)
+}
+
+int tg_entropy_terms_f32(const float* logits, int ld, int n, int k, float w_h, float w_bal, float* dlogits, int ld_d, int accumulate, float* loss,
+                         void* stream) {
+  TG_REQUIRE(logits && loss && n > 0 && k == KC && ld >= KC && (!dlogits || ld_d >= KC), "entropy_terms: bad args (k must be %d)", KC);
+  LOSS_LAUNCH(entropy_terms_kernel, logits, ld, n, w_h, w_bal, dlogits, ld_d, accumulate, loss)
 }
 
 int tg_accuracy_count_f32(const float* logits, int ld, const float* labels, int n, int k, float* counters, void* stream) {

@@ -52,7 +52,8 @@ HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "
 _SCALARS = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint32_t": C.c_uint32, "float": C.c_float}
 _RET = {"int": C.c_int, "int64_t": C.c_int64, "const char*": C.c_char_p}
 _NOCHECK = {"tg_version", "tg_last_error_string", "tg_device_count", "tg_prof_num_classes", "tg_prof_class_name",
-            "tg_colstats_workspace_floats"}
+            "tg_colstats_workspace_floats", "tg_igemm_colsum_supported"}
+_NEGATIVE_IS_ERROR = {"tg_wgrad_splits", "tg_wgrad_workspace_bytes", "tg_filter_workspace_bytes"}     # return a count / size, < 0 on error
 HOST_INT_ARRAYS = {"seg_rows", "tapmap"}          # pointer arguments that are HOST arrays
 
 
@@ -66,7 +67,7 @@ def _ctype_of(decl):
             return C.c_void_p if name == "descs" else C.POINTER(IgemmDesc)
         if typ.count("*") == 2:
             return C.POINTER(C.c_void_p)
-        if name in HOST_INT_ARRAYS:
+        if name in HOST_INT_ARRAYS or (name.endswith("_out") and base == "int32_t"):
             return C.POINTER(C.c_int32)
         if name == "state":
             return C.c_void_p
@@ -126,6 +127,10 @@ def call(name, *args):
     lib = load()
     rc = getattr(lib, name)(*args)
     if name in _NOCHECK:
+        return rc
+    if name in _NEGATIVE_IS_ERROR:
+        if rc < 0:
+            raise TgError("%s failed (%d): %s" % (name, rc, lib.tg_last_error_string().decode()))
         return rc
     if rc != 0:
         raise TgError("%s failed (%d): %s" % (name, rc, lib.tg_last_error_string().decode()))

@@ -50,15 +50,6 @@ def colstats(mode, a_t, ld_a, b_t, ld_b, rows, c, seg_rows, act=None, alpha=0.2,
     return s1, s2
 
 
-_IGEMM_TILES = ((128, 128), (64, 128), (64, 64), (128, 64), (32, 128), (128, 32))     # csrc/igemm.hip igemm_impl candidates
-
-
-def _colsum_tile_exists(c_out, seg_rows):
-    """tg_igemm_colsum_* needs a tile that straddles at most one application boundary: every segment at least as long as
-    the tile (and at most 8 segments)."""
-    return len(seg_rows) <= 8 and any(c_out % bn == 0 and all(r >= bm for r in seg_rows) for bm, bn in _IGEMM_TILES)
-
-
 def _run_prep_plan(cx, plan):
     """tg_filter_prep_multi_f32 for the recorded layers that are not prepared yet; every result goes into the cache tagged with the
     scratch count its layer would have consumed, so that call-site numbering stays what it was in the recording pass."""
@@ -74,24 +65,14 @@ def _run_prep_plan(cx, plan):
         cx.prep_cache[j['key']] = (j['scale'], j['w_oti'], j['w_hwio'], j['bump'], cx.phase)
 
 
-def wgrad_splits(desc, m):
-    """pixel splits of tg_wgrad_f32: fill ONE round of the 512 resident workgroups (256 CUs x 2) as fully as possible —
-    576 blocks take two rounds and run at 56 % — with at least 128 pixels (4 K-tiles) per split."""
-    pick = lambda n: 128 if n % 128 == 0 else (64 if (n % 64 == 0 or n >= 160) else 32)     # csrc/igemm.hip:wgrad_impl
-    ct, nt = pick(desc.ld_in), pick(desc.c_out)
-    tiles = desc.n_taps * -(-desc.ld_in // ct) * -(-desc.c_out // nt)
-    return max(1, min(512 // tiles, m // 128))
-
-
 def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst, wn=None, defer=True):
     """dst[t][c_dim][n_dim] = filter gradient via tg_wgrad_f32 slabs + deterministic reduce.
     wn=(v, g, dv, dg): weight-normalised layer — dst is the gradient of the effective filter (scratch), dv / dg the variables'.
     The tail (slab reduction [+ weight-norm gradient]) is DEFERRED to Context.flush_tails (end of the backward pass / bucket
     boundary), where the tails of all layers go out as three launches; the 512-split first convolution keeps its own reduce."""
     cx = ctx()
-    m = desc.n_img * desc.h_v * desc.w_v
-    ns = wgrad_splits(desc, m)
-    slab = cx.scratch('slab', ns * t * desc.ld_in * desc.c_out)
+    ns = geom.wgrad_splits(desc)                      # pixel split and slab size: the library's rule (tg_wgrad_splits)
+    slab = cx.scratch('slab', geom.wgrad_slab_floats(desc, ns))
     _call('tg_wgrad_f32', desc, _p(in_act_t), _p(dout_t), _p(slab), ns, cx.stream)
     deferred = defer and (cx.tape is not None or cx._phase_depth > 0)
     wide = ns >= 32 and t * c_dim * n_dim <= 65536
@@ -165,7 +146,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     y = cx.new_act(x.n, d.h_out, d.w_out, c_out, ld_out, requires_grad=needs_w or needs_x)
     y.strided_grad_ok = True
     seg_rows = _segs(y, segments)
-    fused = (mobn is not None and train and c_out == co_p and c_out <= 512 and stride == 1 and _colsum_tile_exists(c_out, seg_rows))
+    fused = (mobn is not None and train and c_out == co_p and c_out <= 512 and stride == 1 and geom.colsum_supported(d, seg_rows))
     if fused:
         # convolution + per-(application, channel) sums in one launch, then one fused apply pass (mean, +b, activation, pop_mean)
         b, b_grad, pop = mobn
@@ -241,7 +222,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
             dlist = geom.conv_dgrad(x.n, x.h, x.w, ci_p, co_p, k, stride, padding, ld_out=gx.ld, n_store=ci_p)
             sink = x.grad_sink
             if (_ACTSUM and sink is not None and fresh and len(dlist) == 1 and x.c == ci_p == gx.ld == x.ld and sum(sink[2]) == x.rows
-                    and _colsum_tile_exists(ci_p, sink[2])):
+                    and geom.colsum_supported(dlist[0], sink[2])):
                 # x is the output of a mean-only-BN layer: this launch also applies that layer's activation derivative and sums the
                 # columns per application, so its backward pass needs no statistics pass of its own (tg_mobn_center_f32)
                 nsg = len(sink[2])
@@ -559,7 +540,8 @@ def copy2d(dst_t, ld_d, dst_col, src_t, ld_s, rows, c):
 def copy_rows(dst_t, dst_off, src_t, numel):
     """contiguous device copy (batch concatenation along N)."""
     cx = ctx()
-    _call('tg_copy2d_f32', C.c_void_p(src_t.data_ptr()), numel, C.c_void_p(dst_t.data_ptr() + 4 * dst_off), numel, 1, numel, cx.stream)
+    numel = int(numel)
+    _call('tg_copy2d_f32', C.c_void_p(src_t.data_ptr()), numel, C.c_void_p(dst_t.data_ptr() + 4 * int(dst_off)), numel, 1, numel, cx.stream)
 
 
 def reshape(x, n, h, w, c):
@@ -621,3 +603,73 @@ def concat_batch(acts):
                 off += a.n
         cx.record(bwd)
     return out
+
+
+# ------------------------------------------------------------------ stand-alone activation / batch norm of the reference's free functions
+
+def activation(x, act, alpha=0.2):
+    """y = act(x) as its own launch (an activation CALLED on a tensor, e.g. Good_GAN_cifar10.leakyReLu(x), NN_Base._relu(x)); the models
+    pass their activations as `nonlinearity=` / `activation=` instead and get them fused into the producing kernel's epilogue."""
+    cx = ctx()
+    y = cx.new_act(x.n, x.h, x.w, x.c, x.ld, requires_grad=x.requires_grad)
+    y.strided_grad_ok = True
+    _call('tg_act_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, x.c, ACT[act], alpha, cx.stream)
+    if cx.tape is not None and x.requires_grad:
+        def bwd():
+            gx = cx.grad_of(x)
+            _call('tg_actgrad_f32', y.grad.ptr, y.grad.ld, y.ptr, y.ld, None, 0, 1.0, gx.ptr, gx.ld, x.rows, x.c, ACT[act], alpha, cx.stream)
+        cx.record(bwd)
+    return y
+
+
+def batch_norm_moments(x, scale, beta, pop_mean, pop_var, eps, decay, train, scale_grad=None, beta_grad=None):
+    """nn.batch_norm_impl (Model/nn.py:192-217): tf.nn.moments + tf.nn.batch_normalization with the running statistics updated
+    as pop <- pop*decay + batch*(1-decay) from the BIASED batch variance (tf.nn.moments; contrib's fused batch_norm — ops.batch_norm_train —
+    feeds the unbiased one), or, train=False, normalisation by the running statistics.  Two-pass centred variance as tf.nn.moments."""
+    cx = ctx()
+    c = x.c
+    if not train:
+        return batch_norm_eval(x, scale, beta, pop_mean, pop_var, eps)
+    trains = cx.trains()
+    needs = cx.tape is not None and (x.requires_grad or trains)
+    s1, _ = colstats(0, x.t, x.ld, None, 0, x.rows, c, [x.rows])
+    s2, _ = colstats(4, x.t, x.ld, s1, 0, x.rows, c, [x.rows], alpha=1.0 / x.rows)
+    sc, sh, mean_inv = cx.scratch('bnsc', c), cx.scratch('bnsh', c), cx.scratch('bnmi', 2 * c)
+    _call('tg_bn_finalize_f32', _p(s1), _p(s2), x.rows, c, _p(scale), _p(beta), eps, _p(sc), _p(sh), _p(mean_inv), _p(pop_mean), _p(pop_var), decay, 0,
+          cx.stream)
+    y = cx.new_act(x.n, x.h, x.w, c, x.ld, requires_grad=needs)
+    _call('tg_seg_scale_shift_act_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, c, seg_array([x.rows]), 1, _p(sc), _p(sh), 0, 0.0, cx.stream)
+    if not needs:
+        return y
+
+    def bwd():
+        gy = y.grad
+        assert gy is not None
+        gx = cx.grad_of(x)
+        d1, d2 = colstats(3, gy.t, gy.ld, x.t, x.ld, x.rows, c, [x.rows])
+        abc = cx.scratch('bnabc', 3 * c)
+        want = trains and scale_grad is not None
+        dg = scale_grad if want else cx.scratch('bndg', c)
+        db = beta_grad if want else cx.scratch('bndb', c)
+        _call('tg_bn_bwd_finalize_f32', _p(d1), _p(d2), x.rows, c, _p(scale), _p(mean_inv), _p(abc), _p(dg), _p(db), cx.stream)
+        _call('tg_bn_bwd_apply_f32', gy.ptr, gy.ld, x.ptr, x.ld, gx.ptr, gx.ld, x.rows, c, _p(abc), 0, cx.stream)
+
+    cx.record(bwd)
+    return y
+
+
+def moments_normalize(x, eps, init_scale=1.0):
+    """scale_init * (x - m_init) with m, v = tf.nn.moments(x, all axes but the last), scale_init = init_scale / sqrt(v + eps): the value
+    the data-dependent-initialisation branch (init=True) of the Salimans layers returns (Model/nn.py:230-243,263-277,302-316).
+    Forward only (the reference never differentiates that branch: its models call it once to create variables)."""
+    cx = ctx()
+    c = x.c
+    s1, _ = colstats(0, x.t, x.ld, None, 0, x.rows, c, [x.rows])
+    s2, _ = colstats(4, x.t, x.ld, s1, 0, x.rows, c, [x.rows], alpha=1.0 / x.rows)
+    sc, sh, mi = cx.scratch('bnsc', c), cx.scratch('bnsh', c), cx.scratch('bnmi', 2 * c)
+    g, b = cx.ws('const:init_scale%g' % init_scale, c), cx.ws('const:zeros', max(c, 1024))
+    _call('tg_fill_f32', _p(g), float(init_scale), c, cx.stream)
+    _call('tg_bn_finalize_f32', _p(s1), _p(s2), x.rows, c, _p(g), _p(b), eps, _p(sc), _p(sh), _p(mi), None, None, 0.0, 0, cx.stream)
+    y = cx.new_act(x.n, x.h, x.w, c, x.ld)
+    _call('tg_seg_scale_shift_act_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, c, seg_array([x.rows]), 1, _p(sc), _p(sh), 0, 0.0, cx.stream)
+    return y

@@ -120,6 +120,34 @@ class ParamStore(object):
     def enable_ema(self):
         self.ema = self.p.clone()
 
+    def extend(self, specs):
+        """Append variables (tf.get_variable creating on first use, Context.get_variable): the flat buffers are re-allocated with
+        the old contents in front — offsets of existing variables do not move, device POINTERS do, so this is for graph-build time
+        only (before the first Train.train_iteration captures anything)."""
+        off_p, off_s = self.n_p, (self.n_s if any(not t for _, _, t in self.specs) else 0)
+        for nm, shape, trainable in specs:
+            assert nm not in self.index, nm
+            n = int(np.prod(shape))
+            if trainable:
+                self.index[nm] = ('p', off_p, n, tuple(shape))
+                off_p += pad32(n)
+            else:
+                self.index[nm] = ('s', off_s, n, tuple(shape))
+                off_s += pad32(n)
+            self.specs.append((nm, tuple(shape), trainable))
+
+        def grow(buf, n):
+            if buf.numel() >= n:
+                return buf
+            new = torch.zeros(n, dtype=buf.dtype, device=buf.device)
+            new[:buf.numel()].copy_(buf)
+            return new
+        self.n_p, self.n_s = off_p, max(off_s, 32)
+        self.p, self.g, self.m, self.v = (grow(b, self.n_p) for b in (self.p, self.g, self.m, self.v))
+        self.s = grow(self.s, self.n_s)
+        if self.ema is not None:
+            self.ema = grow(self.ema, self.n_p)
+
     def offset(self, nm):
         """element offset of trainable variable `nm` inside p / g / m / v (the gradient-bucket boundary of the DP exchange)."""
         assert self.index[nm][0] == 'p', nm
@@ -453,6 +481,15 @@ class Context(object):
         finally:
             self.tape, self.train_nets = prev
 
+    @contextlib.contextmanager
+    def no_record(self):
+        """execute the enclosed ops forward-only (nothing goes on the tape)."""
+        prev, self.tape = self.tape, None
+        try:
+            yield
+        finally:
+            self.tape = prev
+
     def run_tape(self, tape):
         for fn in reversed(tape):
             if fn is not BUCKET_BOUNDARY:
@@ -493,6 +530,23 @@ class Context(object):
         """device tensor of variable '<scope>/<leaf>' (tf.get_variable with reuse=True)."""
         full = self.scope_name(leaf)
         return self.store_of(full).value(full)
+
+    def get_variable(self, leaf, shape, initializer, trainable=True):
+        """tf.get_variable(leaf, shape, initializer=..., trainable=...) under the current variable scope: the existing variable
+        (reuse=True) or a new one appended to the store of the scope's root (created on first use the way the reference's layer
+        functions create theirs, Model/nn.py:194-201,227-237).  initializer: float (constant) or callable(shape) -> array."""
+        full = self.scope_name(leaf)
+        root = full.split('/')[0]
+        st = self.stores.get(root)
+        if st is None:
+            st = self.stores[root] = ParamStore(root, [], self.device)
+        if full not in st.index:
+            st.extend([(full, tuple(int(d) for d in shape), trainable)])
+            val = initializer(tuple(shape)) if callable(initializer) else np.full(shape, initializer, np.float32)
+            st.set(full, val)
+        # the same bytes may be declared under two views (the classifier's first filter: [3,3,3,128] = [27,128])
+        assert int(np.prod(st.shape(full))) == int(np.prod(shape)), (full, st.shape(full), shape)
+        return st.value(full)
 
     def var_grad(self, leaf):
         full = self.scope_name(leaf)

@@ -1,0 +1,85 @@
+"""Descriptor builders behind the C ABI (csrc/geom.cpp; include/tg_kernels.h "descriptor builders and workspace sizes") against
+the independent Python restatement of round 1 (tests/geom_reference.py), field by field over a sweep of shapes, plus the tile /
+split rules that used to be mirrored in Python.  Host only: no GPU call is made (the library loads without a device)."""
+import ctypes as C
+import itertools
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tensorflow-implementation-of-triple-gan_amd'))
+from tg import geom, lib  # noqa: E402
+import geom_reference as R  # noqa: E402
+
+FIELDS = [f for f, _ in lib.IgemmDesc._fields_]
+
+
+def same(a, b):
+    for f in FIELDS:
+        va, vb = getattr(a, f), getattr(b, f)
+        if f in ('dy', 'dx', 'tapw'):
+            va, vb = list(va)[:a.n_taps], list(vb)[:b.n_taps]
+        if f == 'alpha':
+            assert abs(va - vb) < 1e-7, f
+        else:
+            assert va == vb, (f, va, vb)
+
+
+def test_conv_descriptors_equal_the_restatement():
+    for n, h, w, k, s, pad in itertools.product((1, 3), (6, 9, 32), (6, 7), (1, 3, 5), (1, 2), ('SAME', 'VALID')):
+        if pad == 'VALID' and (h < k or w < k):
+            continue
+        for ld_in, c_out, ld_out, n_store in ((32, 64, None, None), (96, 32, 40, 7)):
+            same(geom.conv_fwd(n, h, w, ld_in, c_out, k, s, pad, ld_out=ld_out, n_store=n_store, act='lrelu', alpha=0.3),
+                 R.conv_fwd(n, h, w, ld_in, c_out, k, s, pad, ld_out=ld_out, n_store=n_store, act='lrelu', alpha=0.3))
+            same(geom.conv_wgrad(n, h, w, ld_in, c_out, k, s, pad), R.conv_wgrad(n, h, w, ld_in, c_out, k, s, pad))
+            got, ref = geom.conv_dgrad(n, h, w, ld_in, c_out, k, s, pad, ld_out=ld_out and ld_in + 32), R.conv_dgrad(n, h, w, ld_in, c_out, k, s, pad,
+                                                                                                                    ld_out=ld_out and ld_in + 32)
+            assert len(got) == len(ref)
+            for a, b in zip(got, ref):
+                same(a, b)
+
+
+def test_deconv_and_dense_descriptors_equal_the_restatement():
+    for n, h, w in ((2, 4, 4), (5, 8, 6), (1, 16, 16)):
+        for ld_in, co_p, ld_out, n_store, act in ((544, 256, None, None, 'relu'), (160, 32, 3, 3, 'tanh')):
+            got, ref = geom.deconv_fwd(n, h, w, ld_in, co_p, ld_out=ld_out, n_store=n_store, act=act), R.deconv_fwd(n, h, w, ld_in, co_p, ld_out=ld_out,
+                                                                                                                  n_store=n_store, act=act)
+            assert len(got) == len(ref) == 4
+            for a, b in zip(got, ref):
+                same(a, b)
+            same(geom.deconv_dgrad(n, h, w, ld_in, co_p), R.deconv_dgrad(n, h, w, ld_in, co_p))
+            same(geom.deconv_wgrad(n, h, w, co_p, ld_in), R.deconv_wgrad(n, h, w, co_p, ld_in))
+        d, ng, tm = geom.deconv_fwd_merged(n, h, w, 160, 3, 3, n_store=3, act='tanh')
+        dr, ngr, tmr = R.deconv_fwd_merged(n, h, w, 160, 3, 3, n_store=3, act='tanh')
+        same(d, dr)
+        assert (ng, tm) == (ngr, tmr)
+    same(geom.dense_fwd(100, 128, 8192, act='relu'), R.dense_fwd(100, 128, 8192, act='relu'))
+    same(geom.dense_fwd(7, 160, 32, ld_out=1, n_store=1), R.dense_fwd(7, 160, 32, ld_out=1, n_store=1))
+    for a, b in zip(geom.dense_fwd_splitk(130, 3072, 3072, 4), R.dense_fwd_splitk(130, 3072, 3072, 4)):
+        same(a, b)
+
+
+def test_tile_and_colsum_rules_live_in_the_library():
+    """what tg/ops.py mirrored in Python in round 1 (the candidate tile list, the filter-gradient tile pick) is now asked of the library."""
+    def tile(d, segs=None, bf16=False):
+        bm, bn = C.c_int32(), C.c_int32()
+        arr = (C.c_int32 * len(segs))(*segs) if segs else None
+        lib.call('tg_igemm_tile', C.byref(d), 1, arr, len(segs) if segs else 0, int(bf16), C.byref(bm), C.byref(bn))
+        return bm.value, bn.value
+    big = geom.conv_fwd(250, 32, 32, 128, 128, 3, 1, 'SAME')
+    assert tile(big) == (64, 64)                                     # 64x64 tiles interleave their epilogues
+    assert tile(big, bf16=True) == (128, 128)                        # bf16 operands: conversion work favours the large tile
+    assert tile(geom.dense_fwd(100, 128, 8192)) in ((32, 128), (64, 128), (64, 64), (128, 128), (128, 64))
+    # colsum: every segment at least as long as some tile that divides c_out, at most 8 segments, rows must add up
+    assert geom.colsum_supported(big, [50 * 1024, 50 * 1024, 50 * 1024, 100 * 1024])
+    assert not geom.colsum_supported(big, [250 * 1024 - 16, 16])     # a 16-row segment is shorter than every tile
+    assert not geom.colsum_supported(big, [1024] * 9)
+    assert not geom.colsum_supported(big, [1024, 2048])              # does not cover the launch
+    small = geom.conv_fwd(4, 6, 6, 512, 256, 1, 1, 'SAME')           # 144 rows, two applications of 72: only the 64- and 32-row tiles
+    assert geom.colsum_supported(small, [72, 72]) and tile(small, [72, 72])[0] <= 64
+    from tg.lib import TgError
+    with pytest.raises(TgError, match="no tile fits"):
+        tile(small, [20, 124])                                        # a 20-row application: shorter than the smallest (32-row) tile

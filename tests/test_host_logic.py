@@ -79,20 +79,27 @@ def test_deconv_geometry():
 
 
 def test_same_padding_matches_tf_rule():
-    assert geom.same_pad(32, 3, 2) == (16, 0, 1)      # extra pixel goes after
-    assert geom.same_pad(32, 3, 1) == (32, 1, 1)
-    assert geom.same_pad(8, 5, 2) == (4, 1, 2)
-    assert geom.out_size(8, 3, 1, 'VALID') == (6, 0)
+    """TF's SAME rule as the library's descriptors encode it: (output size, padding before) = first tap's offset negated."""
+    def out_before(n, k, s, pad):
+        d = geom.conv_fwd(1, n, n, 32, 32, k, s, pad)
+        return d.h_out, -d.dy[0]
+    assert out_before(32, 3, 2, 'SAME') == (16, 0)      # total 1: the extra pixel goes after
+    assert out_before(32, 3, 1, 'SAME') == (32, 1)
+    assert out_before(8, 5, 2, 'SAME') == (4, 1)        # total 3: 1 before, 2 after
+    assert out_before(8, 3, 1, 'VALID') == (6, 0)
+    from tg.lib import TgError
+    with pytest.raises(TgError, match="conv2d_desc_fwd"):
+        geom.conv_fwd(1, 2, 2, 32, 32, 3, 1, 'VALID')     # window larger than the image
 
 
 def test_wgrad_splits_fill_one_round():
-    from tg import ops
     d = geom.conv_wgrad(250, 32, 32, 128, 128, 3, 1, 'SAME')
-    assert ops.wgrad_splits(d, 250 * 1024) == 56                    # 9 tiles * 56 = 504 <= 512 resident workgroups
+    assert geom.wgrad_splits(d) == 56                                # 9 tiles * 56 = 504 <= 512 resident workgroups
+    assert geom.wgrad_slab_floats(d, 56) == 56 * 9 * 128 * 128
     d = geom.conv_wgrad(250, 16, 16, 256, 256, 3, 1, 'SAME')
-    assert ops.wgrad_splits(d, 250 * 256) == 14
+    assert geom.wgrad_splits(d) == 14
     d = geom.dense_fwd(100, 128, 8192)
-    assert ops.wgrad_splits(d, 100) == 1                             # never an empty split
+    assert geom.wgrad_splits(d) == 1                                 # never an empty split
 
 
 def test_param_store_layout_and_roundtrip():

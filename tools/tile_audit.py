@@ -36,8 +36,8 @@ for (M, N, taps, ld, h, w, s), cnt in sorted(shapes.items(), key=lambda kv: -kv[
         continue
     d = None
     for pad in ('SAME', 'VALID'):
-        ho = geom.out_size(h, k, s, pad)[0]
-        wo = geom.out_size(w, k, s, pad)[0]
+        g0 = geom.conv_fwd(1, h, w, 32, 32, k, s, pad)
+        ho, wo = g0.h_out, g0.w_out
         if ho > 0 and wo > 0 and M % (ho * wo) == 0:
             n = M // (ho * wo)
             d = geom.conv_fwd(n, h, w, ld, N, k, s, pad)
