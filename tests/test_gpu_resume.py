@@ -90,3 +90,64 @@ def test_train_writes_and_resumes_from_the_reference_artefacts(tmp_path):
     assert [h['epoch'] for h in hist2] == [3]
     assert 'model_0003.ckpt.npz' in os.listdir(os.path.join(save, runs[0]))
     assert int(tr2.cx.stores['classifier'].step.item()) == 3 * 3                       # 3 iterations per epoch, 3 epochs
+
+
+@pytest.mark.parametrize("data", ['cifar10', 'mnist', 'svhn'])
+def test_checkpoint_holds_exactly_the_variables_tensorflow_would_save(tmp_path, data):
+    """the key set of a checkpoint equals the names tf.train.Saver() would write for the reference's graph — derived
+    independently of the package's own variable tables from the reference's scopes (oracle/tf_names.py) — with two documented
+    substitutions: TensorFlow's six beta1_power / beta2_power scalars are replaced by one step count per optimiser (tg/adam_step/<net>),
+    and tg/rng_state, tg/epoch have no TensorFlow counterpart."""
+    from oracle import tf_names
+    from Training.Saver import Saver
+    if data == 'cifar10':
+        tr = G.fresh_trainer(G.make_config(SIZES))
+    else:
+        from Model.Good_GAN import Good_GAN
+        tr = G.fresh_trainer(G.make_config_goodgan(data, SIZES), None, Good_GAN)
+    saver = Saver(str(tmp_path))
+    saver.set_save_path(comments='names')
+    keys = set(np.load(saver.save(tr, 'model_0001.ckpt')).files)
+    extras = {k for k in keys if k.startswith('tg/')}
+    assert extras == {'tg/adam_step/good_generator', 'tg/adam_step/discriminator', 'tg/adam_step/classifier', 'tg/rng_state', 'tg/epoch'}
+    want = set(tf_names.saver_variables(data)) - set(tf_names.NON_SLOT)
+    assert keys - extras == want, (sorted((keys - extras) - want)[:5], sorted(want - (keys - extras))[:5])
+    for name in ('classifier/conv1_1/V', 'classifier/NiN1/NiN1/V', 'good_generator/gg_h0_lin/gg_h0_lin/kernel') if data == 'cifar10' else ():
+        assert {name, name + '/Adam_optimizer', name + '/Adam_optimizer_1'} <= keys               # the names SURVEY §8f spells out
+    assert 'classifier/NiN1/NiN1/V/ExponentialMovingAverage' in keys or data != 'cifar10'
+
+
+def test_restored_checkpoint_reproduces_the_golden_evaluation(tmp_path):
+    """save -> load into a differently initialised process state -> the restored model's evaluation logits, accuracy and sampler output are
+    the committed golden vectors (outputs of the oracle, tests/golden/cifar10_small_k10.npz), not merely what the saving run computed."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_golden as M
+    from oracle import step_cifar10 as S
+    from tg.runtime import InjectedRNG
+    from Training.Saver import Saver
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cifar10_small_k10.npz'))
+    a = G.fresh_trainer(G.make_config(M.SIZES), S.init_params(0))
+    saver = Saver(str(tmp_path))
+    saver.set_save_path(comments='golden')
+    saver.save(a, 'model_0007.ckpt')
+    b = G.fresh_trainer(G.make_config(M.SIZES, SEED=4321), S.init_params(77))                     # other weights everywhere
+    cx = b.cx
+    xt, yt, noise = M.test_split()
+    z, y = M.sample_latents()
+
+    def logits_and_acc():
+        cx.rng = InjectedRNG({'val/C/noise': noise}, cx.device)
+        with cx.phase_scope('val', record=False):
+            with cx.rng_scoped('val/C'):
+                lg, _ = b.model.classifier(b.model.zca().apply(cx.from_numpy(xt)), False)
+        cx.rng = InjectedRNG({'val/C/noise': noise}, cx.device)
+        return lg.numpy(), b.evaluate([(xt, yt)])
+
+    before, _ = logits_and_acc()
+    assert G.rel_err(before, g['logits_init']) > 1e-2                                            # b really starts elsewhere
+    assert Saver(str(tmp_path)).restore(b) == 7
+    after, acc = logits_and_acc()
+    assert G.rel_err(after, g['logits_init']) < 2e-4
+    assert abs(acc - float(g['acc_init'])) <= 1.0 / M.N_TEST + 1e-9
+    assert G.rel_err(b.sample(z, y), g['sample_init']) < 2e-4

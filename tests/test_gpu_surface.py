@@ -161,17 +161,18 @@ def test_loss_gan_equals_its_reassembly_from_the_helper_heads(plain):
     ref = OF.loss_gan([None, d_real.astype(np.float64), None, d_fake.astype(np.float64), None, d_unl.astype(np.float64)],
                       [a.astype(np.float64) for a in (c_real, c_unl, c_unl_d, c_fake, c_rep)], [y_g.astype(np.float64), y_l.astype(np.float64)], LAMBDA, True)
     with cx.phase_scope('lg', record=False):
-        A = lambda x: cx.from_numpy(x, ld=32 if x.shape[1] == 10 else None)
+        A = lambda x: cx.from_numpy(x, ld=32 if x.shape[1] == 10 else None)     # logits: channel-padded as the networks emit them
+        Y = lambda y: cx.from_numpy(y)                                          # labels: dense [n][10] (the placeholders' layout)
         D = [None, A(d_real), None, A(d_fake), None, A(d_unl)]
         C = [A(c_real), A(c_unl), A(c_unl_d), A(c_fake), A(c_rep)]
-        fused = [float(v) for v in tr._loss_GAN(D, C, [A(y_g), A(y_l)], LAMBDA)]
+        fused = [float(v) for v in tr._loss_GAN(D, C, [Y(y_g), Y(y_l)], LAMBDA)]
         dr, df, du = A(d_real), A(d_fake), A(d_unl)
         d_loss = float(tr._sigmoid_cross_entopy_w_logits(1.0, dr)) + 0.5 * float(tr._sigmoid_cross_entopy_w_logits(0.0, df)) \
             + 0.5 * float(tr._sigmoid_cross_entopy_w_logits(0.0, du))
         g_loss = 0.5 * float(tr._sigmoid_cross_entopy_w_logits(1.0, A(d_fake)))
         cu = A(c_unl)
-        c_real_term = float(tr._softmax_cross_entropy_loss_w_logits(A(y_l), A(c_real))) + 1e-6 * float(tr._entropy(cu)) + 1e-3 * float(tr._balance_entropy(cu))
-        c_fake_term = float(tr._softmax_cross_entropy_loss_w_logits(A(y_g), A(c_fake)))
+        c_real_term = float(tr._softmax_cross_entropy_loss_w_logits(Y(y_l), A(c_real))) + 1e-6 * float(tr._entropy(cu)) + 1e-3 * float(tr._balance_entropy(cu))
+        c_fake_term = float(tr._softmax_cross_entropy_loss_w_logits(Y(y_g), A(c_fake)))
     for a, e in zip(fused, ref):
         assert abs(a - e) <= 2e-5 * max(1.0, abs(e)), (fused, ref)
     assert abs(d_loss - ref[0]) < 2e-5 and abs(g_loss - ref[1]) < 2e-5
