@@ -338,6 +338,14 @@ int tg_gavgpool_concat_f32(const float* x, int ld_x, int c, const float* y, int 
 int tg_gavgpool_bwd_f32(const float* dfeat, int ld_d, const float* yact, int ld_y, float* out, int ld_out, int n, int hw, int c, int act,
                         float alpha, void* stream);
 int tg_copy2d_f32(const float* src, int64_t ld_s, float* dst, int64_t ld_d, int64_t rows, int64_t c, void* stream);
+/* up to 16 contiguous copies dst[0:n) = src[0:n) in ONE launch: tf.concat along the batch axis (Model/Good_GAN_cifar10.py:258-259, the
+ * batched network applications of this package) and the feed of one iteration's placeholders (Training/Train_goodGAN.py:249-263). */
+typedef struct tg_copy_job {
+  const float* src;
+  float* dst;
+  int64_t n;
+} tg_copy_job;
+int tg_copy_multi_f32(const tg_copy_job* jobs, int n_jobs, void* stream);
 int tg_fill_f32(float* dst, float value, int64_t n, void* stream);
 /* out[m][n] = bias[n] + sum_s part[m][s][n] (bias may be NULL): finishes a dense product whose reduction dimension was split
  * into s_dim sub-problems of one tg_igemm_multi_f32 launch (skinny GEMMs such as the ZCA product: few rows, long K). */

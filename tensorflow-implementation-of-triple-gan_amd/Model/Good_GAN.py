@@ -178,13 +178,13 @@ class Good_GAN(model_base.NN_Base):
                     h = self._WN_dense(ops.cond_concat(h, y.t, y.c), (1000, 500, 250, 250, 250)[i], 'd_h%d_wndense0' % i, init=False, activation=lre)
                     h = self._add_noise(h, stddev=0.2)
                 return self._d_out(self._WN_dense(ops.cond_concat(h, y.t, y.c), 1, 'd_h5_wndense0', init=False, narrow=True), want_prob)
-            image = self._drop_out(image, 0.2, True)                                           # :126-165
+            image = self._drop_out(image, 0.2, True, fuse_next=True)                           # :126-165
             h0 = self._WN_conv2d(self._conv_cond_concat(image, y), 32, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h0_wnconv0", activation=lre)
             h0 = self._WN_conv2d(self._conv_cond_concat(h0, y), 32, k_h=3, k_w=3, d_h=2, d_w=2, init=False, name="d_h0_wnconv1", activation=lre)
-            h0 = self._drop_out(h0, 0.2, True)
+            h0 = self._drop_out(h0, 0.2, True, fuse_next=True)
             h1 = self._WN_conv2d(self._conv_cond_concat(h0, y), 64, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h1_wnconv0", activation=lre)
             h1 = self._WN_conv2d(self._conv_cond_concat(h1, y), 64, k_h=3, k_w=3, d_h=2, d_w=2, init=False, name="d_h1_wnconv1", activation=lre)
-            h1 = self._drop_out(h1, 0.2, True)
+            h1 = self._drop_out(h1, 0.2, True, fuse_next=True)
             h2 = self._WN_conv2d(self._conv_cond_concat(h1, y), 128, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h2_wnconv0", activation=lre)
             h2 = ops.cond_concat(h2, _twice(y), 2 * y.c)                                        # y is concatenated twice (:151-153)
             h2 = self._WN_conv2d(h2, 128, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h2_wnconv1", activation=lre)

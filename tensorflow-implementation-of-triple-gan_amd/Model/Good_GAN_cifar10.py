@@ -44,10 +44,16 @@ G_DECONVS = [('gg_dconv0', 256), ('gg_dconv1', 128), ('gg_dconv2', 3)]      # (:
 
 class Good_GAN_cifar10(model_base.NN_Base):
     C_CONVS, D_CONVS, G_DECONVS = C_CONVS, D_CONVS, G_DECONVS
-    # data-parallel gradient buckets of the classifier: the variables created from C_BUCKET_FIRST on (87 % of
-    # the 12.5 MB) are final when the backward pass has returned to the end of block C_BUCKET_AFTER; their all-reduce then
-    # runs on RCCL's stream beside the backward pass of the first block
-    C_BUCKET_AFTER, C_BUCKET_FIRST = 'conv1_3', 'classifier/conv2_1/V'
+    # Data-parallel gradient buckets: per network, the first variable (creation order) of every bucket after the first.
+    # A bucket is one contiguous slice of the network's flat gradient buffer; the forward pass marks the matching boundary right before
+    # the layer that owns the variable (Context.grad_bucket_boundary), so that the backward pass — run bucket by bucket — has the slice
+    # from that variable on final when it comes back to the mark, and its all-reduce runs on the exchange stream beside the rest:
+    #   classifier     [conv2_1 ... output_dense] (87 % of 12.5 MB) beside the backward pass of the first block, then [conv1_1 ... conv1_3]
+    #   generator      [gg_dconv0 ... gg_dconv2] (17 of 20.5 MB; the 13 MB gg_dconv0 filter gradient is final here) beside bn0 / gg_h0_lin
+    #   discriminator  one bucket per resolution stage: [conv2d_20 ... lin], [conv2d_10, conv2d_11], [conv2d_00, conv2d_01]
+    GRAD_BUCKETS = {'classifier': ['classifier/conv2_1/V'],
+                    'good_generator': ['good_generator/gg_dconv0/gg_dconv0/kernel'],
+                    'discriminator': ['discriminator/conv2d_10/conv2d_10/kernel', 'discriminator/conv2d_20/conv2d_20/kernel']}
 
     def __init__(self, config):
         super(Good_GAN_cifar10, self).__init__(config.BATCH_NORM_DECAY, config.BATCH_NORM_EPSILON)
@@ -106,6 +112,11 @@ class Good_GAN_cifar10(model_base.NN_Base):
             cx.stores[net] = st
         cx.stores['classifier'].enable_ema()              # Train_goodGAN.py:101-103
 
+    def _bucket_mark(self, net, first_variable):
+        """a gradient-bucket boundary in front of the layer that owns `first_variable` (GRAD_BUCKETS)."""
+        if first_variable in self.GRAD_BUCKETS.get(net, ()):
+            ctx().grad_bucket_boundary(net)
+
     # ------------------------------------------------------------------ activations
     def leakyReLu(self, x, alpha=0.2, name=None):
         """relu(x) - alpha*relu(-x) (:19-27).  Called on a tensor it is one elementwise launch; passed as `nonlinearity=` /
@@ -130,6 +141,7 @@ class Good_GAN_cifar10(model_base.NN_Base):
             h0 = ops.reshape(self._batch_norm_contrib(_dense_view(h0), 'gg_bn0', train=True), z.n, 4, 4, 512)
             h = h0
             for i, (name, cout) in enumerate(self.G_DECONVS):                        # [8,8], [16,16], [32,32]
+                self._bucket_mark('good_generator', 'good_generator/%s/%s/kernel' % (name, name))
                 h = self._conv_cond_concat(h, y)
                 if i + 1 < len(self.G_DECONVS):
                     h = self._deconv2d(h, cout, k_w=5, k_h=5, d_w=2, d_h=2, name=name, activation=self._relu)
@@ -150,12 +162,14 @@ class Good_GAN_cifar10(model_base.NN_Base):
         cx = ctx()
         lre = self.leakyReLu
         with cx.variable_scope('discriminator'):
-            image = self._drop_out(image, 0.2, True)
+            image = self._drop_out(image, 0.2, True, fuse_next=True)
             h2 = image
             for name, cout, stride, drop in self.D_CONVS:
+                self._bucket_mark('discriminator', 'discriminator/%s/%s/kernel' % (name, name))
                 h2 = self._conv2d(self._conv_cond_concat(h2, y), cout, k_h=3, k_w=3, d_h=stride, d_w=stride, name=name, activation=lre)
                 if drop:
-                    h2 = self._drop_out(_dense_view(h2), 0.2, True)
+                    h2 = self._drop_out(_dense_view(h2), 0.2, True, fuse_next=True)
+            assert h2.pending is None, "a dropout behind the last convolution has no concat to fuse into"
             h3 = ops.global_avgpool_concat(h2, y.t, y.c)                             # avg_pool 8 + squeeze + concat y
             h3 = self._linear_fc(h3, 1, 'lin', narrow=True)
         return (self._sigmoid_no_grad(h3) if want_prob else None), h3
@@ -179,9 +193,8 @@ class Good_GAN_cifar10(model_base.NN_Base):
             noise = cx.rng.normal(cx, 'noise', inp.rows * inp.c, 0.15)
             x = ops.im2col3x3_add(inp, noise)
             for i, (name, cout, pad, pool) in enumerate(self.C_CONVS):
+                self._bucket_mark('classifier', 'classifier/%s/V' % name)
                 x = nn.conv2d_WN(x, num_filters=cout, name=name, pad=pad, filter_size=[1, 1] if i == 0 else [3, 3], **kw)
-                if pool and name == self.C_BUCKET_AFTER:
-                    cx.grad_bucket_boundary()                                        # DP: gradients of the later layers are final here
                 if pool:                                                             # max_pool_k + dropout_k (:123-124,142-143)
                     mask = None
                     if is_training:

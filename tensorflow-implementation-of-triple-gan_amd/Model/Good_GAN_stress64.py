@@ -20,7 +20,7 @@ class Good_GAN_stress64(Good_GAN_cifar10):
                ('conv2d_20', 128, 1, False), ('conv2d_21', 128, 2, True), ('conv2d_30', 256, 1, False), ('conv2d_31', 256, 1, False)]
     G_DECONVS = [('gg_dconv0', 256), ('gg_dconv1', 128), ('gg_dconv2', 64), ('gg_dconv3', 3)]
     CONSISTENCY = True
-    C_BUCKET_AFTER, C_BUCKET_FIRST = 'conv0_3', 'classifier/conv1_1/V'
+    GRAD_BUCKETS = dict(Good_GAN_cifar10.GRAD_BUCKETS, classifier=['classifier/conv1_1/V'])        # the first block here is conv0_*
 
     def zca(self):
         return None

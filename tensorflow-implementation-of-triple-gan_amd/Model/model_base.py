@@ -160,14 +160,15 @@ class NN_Base(object):
         """Concatenate conditioning vector on feature map axis (modle_base.py:239-244); y: Act [N,ncls]."""
         return ops.cond_concat(x, y.t, y.c)
 
-    def _drop_out(self, x, rate=0.5, train=False, name=None):
-        """tf.layers.dropout (modle_base.py:190-191): x*mask/keep with a floor(keep+U) keep-mask."""
+    def _drop_out(self, x, rate=0.5, train=False, name=None, fuse_next=False):
+        """tf.layers.dropout (modle_base.py:190-191): x*mask/keep with a floor(keep+U) keep-mask.  fuse_next (extension): the
+        result goes straight into _conv_cond_concat, which applies the mask in its own launch (ops.scale_mask(defer=True))."""
         if not train:
             return x
         cx = ctx()
         mask = cx.rng.keep_mask(cx, name or cx.next_rng_name('drop'), x.rows * x.c, 1.0 - rate)
         assert x.ld == x.c
-        return ops.scale_mask(x, mask, 1.0 / (1.0 - rate))
+        return ops.scale_mask(x, mask, 1.0 / (1.0 - rate), defer=fuse_next)
 
     def _add_noise(self, inputs, mean=0.0, stddev=0.001, name=None):
         """inputs + N(mean, stddev) (modle_base.py:193-202) on a dense activation; the gradient passes through."""

@@ -52,6 +52,7 @@ class Train(Train_base):
         self.loss_dev = torch.zeros(3, dtype=torch.float32, device=cx.device)    # d_loss, g_loss, c_loss
         self.model = None
         self._graphs = None
+        self._rest = {}                  # solver run -> (unexecuted head of its backward tape, call-site counter): bucketed backward passes
         self._warm = False
         self._warm_keys = set()
         self.iteration = 0
@@ -103,7 +104,8 @@ class Train(Train_base):
         self.hyper.copy_(torch.from_numpy(vals))
 
     # ------------------------------------------------------------------ the three solver runs
-    def _d_forward_backward(self):
+    def _d_forward_backward(self, split=False):
+        """split: stop the backward pass at the discriminator's last gradient-bucket boundary (the rest runs in _backward_rest)."""
         c, cx, m = self.config, self.cx, self.model
         with cx.phase_scope('D', train_nets=('discriminator',)):
             # The G-update that follows runs the generator on the same feed with the same (not yet updated) weights, and the
@@ -126,9 +128,9 @@ class Train(Train_base):
             with cx.rng_scoped('D/D'):
                 _, d_logits = m.discriminator(ximg, yall, want_prob=False)
             self._d_loss(d_logits, c.BATCH_SIZE_L_D + c.BATCH_SIZE_U_D, c.BATCH_SIZE_G, c.BATCH_SIZE_U_C, self.loss_dev[0:1])
-            cx.backward()
+            self._rest['D'] = (cx.backward(stop_at_boundary='discriminator' if split else False), cx.counter)
 
-    def _g_forward_backward(self):
+    def _g_forward_backward(self, split=False):
         cx, m = self.cx, self.model
         with cx.phase_scope('G', train_nets=('good_generator',)):
             saved = getattr(self, '_g_saved', None)
@@ -140,12 +142,13 @@ class Train(Train_base):
             with cx.rng_scoped('G/D'):
                 _, d_fake = m.discriminator(G, self.y_g_ph, want_prob=False)
             self._g_loss(d_fake, self.loss_dev[1:2])
-            cx.backward()
-            if g_tape is not None:
-                cx.run_tape(g_tape)
+            rest = cx.backward(stop_at_boundary='good_generator' if (split and g_tape is None) else False)
+            if g_tape is not None:                      # the discriminator's input gradient is complete: now the kept generator tape
+                rest = cx.run_tape(g_tape, stop_at_boundary='good_generator' if split else False)
+            self._rest['G'] = (rest, cx.counter)
 
     def _c_forward_backward(self, split=False):
-        """split: stop the backward pass at the model's gradient-bucket boundary (the rest runs in _c_backward_rest)."""
+        """split: stop the backward pass at the classifier's last gradient-bucket boundary (the rest runs in _backward_rest)."""
         c, cx, m = self.config, self.cx, self.model
         rep = bool(getattr(m, 'CONSISTENCY', False))       # Good_GAN_cifar10 only: second stochastic pass on x_u_c
         with cx.phase_scope('C', train_nets=('classifier',)):
@@ -164,14 +167,15 @@ class Train(Train_base):
                 _, d_unl = m.discriminator(self.x_u_c_ph, oh_unl, want_prob=False)
             self._c_loss(c_logits, segs[0], segs[1], segs[1] if rep else 0, G.n, self.y_l_c_ph, self.y_g_ph, d_unl,
                          self.hyper[2:4], self.loss_dev[2:3])
-            self._c_rest = (cx.backward(stop_at_boundary=split), cx.counter)
+            self._rest['C'] = (cx.backward(stop_at_boundary='classifier' if split else False), cx.counter)
 
-    def _c_backward_rest(self):
-        rest, counter = self._c_rest
-        self._c_rest = None
+    def _backward_rest(self, phase, net, split):
+        """continue the backward pass of solver run `phase` — down to the trained network's next bucket boundary (split) or to its end."""
+        rest, counter = self._rest[phase]
         if rest:
-            with self.cx.phase_scope('C', train_nets=('classifier',), counter=counter):
-                self.cx.run_tape(rest)
+            with self.cx.phase_scope(phase, train_nets=(net,), counter=counter):
+                rest = self.cx.run_tape(rest, stop_at_boundary=net if split else False)
+                self._rest[phase] = (rest, self.cx.counter)
 
     def _c_apply(self):
         st = self.cx.stores['classifier']
@@ -180,43 +184,67 @@ class Train(Train_base):
         lib.call('tg_ema_f32', lib.ptr(st.ema), lib.ptr(st.p), st.n_p, 0.9999, self.cx.stream)
         self.cx.rng.advance(self.cx)
 
+    def _bucket_slices(self, net):
+        """the flat gradient buffer of `net` cut at the model's GRAD_BUCKETS, in the order the backward pass completes them (last
+        variables first); one slice — the whole buffer — without replicas."""
+        st = self.cx.stores[net]
+        names = getattr(self.model, 'GRAD_BUCKETS', {}).get(net, ())
+        if not tgdist.active() or getattr(self.config, 'NO_GRAD_BUCKETS', False) or not names:
+            return [st.g]
+        offs = [0] + sorted(st.offset(n) for n in names) + [st.n_p]
+        return [st.g[offs[i]:offs[i + 1]] for i in range(len(offs) - 2, -1, -1)]
+
+    def _phase_segments(self, phase, net, first_fn, before=None):
+        """[(callable, gradient slice to exchange once it has run)] of one solver run: the forward pass + the backward pass down to the
+        last bucket boundary, then one segment per remaining bucket.  `before` (the previous network's optimiser step) opens the first."""
+        slices = self._bucket_slices(net)
+        split = len(slices) > 1
+        head = (lambda: first_fn(split)) if before is None else (lambda: (before(), first_fn(split)))
+        segs = [(head, slices[0])]
+        for k, sl in enumerate(slices[1:]):
+            last = k == len(slices) - 2
+            segs.append((lambda last=last: self._backward_rest(phase, net, not last), sl))
+        return segs
+
     def _segments(self, pre_train=False):
-        """[(callable, flat gradient range to exchange afterwards or None, asynchronous?)] — each callable is one hipGraph.
-        With more than one replica the classifier's backward pass is cut at the model's bucket boundary: the gradients of
-        the later layers are all-reduced on RCCL's stream while the first block's backward pass still runs."""
+        """[(callable, flat gradient slice to exchange afterwards or None, wait for the pending exchanges first?)] — each callable is
+        one hipGraph.  With replicas every backward pass is cut at the model's bucket boundaries: a finished bucket is all-reduced on
+        the exchange stream while the next segment (the rest of the backward pass) runs; the optimiser step of a network opens the
+        next solver run's first segment and waits for that network's buckets."""
         st = self.cx.stores
         w = 1.0 / self.world
-        gC = st['classifier'].g
-        first = getattr(self.model, 'C_BUCKET_FIRST', None)
-        split = tgdist.active() and first is not None and not getattr(self.config, 'NO_GRAD_BUCKETS', False)
-        if split:
-            off = st['classifier'].offset(first)
-            c_bwd = [(lambda: self._c_forward_backward(True), gC[off:], True), (self._c_backward_rest, gC[:off], False)]
+        if pre_train:                                          # :182-226: pre-training runs c_solver only
+            phases = [self._phase_segments('C', 'classifier', self._c_forward_backward)]
         else:
-            c_bwd = [(self._c_forward_backward, gC, False)]
-        if pre_train:                                      # :182-226 only c_solver runs
-            return c_bwd + [(self._c_apply, None, False)]
-        c_bwd[0] = ((lambda f=c_bwd[0][0]: (self._train_op(self.g_optimizer, st['good_generator'], w), f())),) + c_bwd[0][1:]
-        return [
-            (self._d_forward_backward, st['discriminator'].g, False),
-            (lambda: (self._train_op(self.d_optimizer, st['discriminator'], w), self._g_forward_backward()), st['good_generator'].g, False),
-        ] + c_bwd + [(self._c_apply, None, False)]
+            phases = [self._phase_segments('D', 'discriminator', self._d_forward_backward),
+                      self._phase_segments('G', 'good_generator', self._g_forward_backward,
+                                           lambda: self._train_op(self.d_optimizer, st['discriminator'], w)),
+                      self._phase_segments('C', 'classifier', self._c_forward_backward,
+                                           lambda: self._train_op(self.g_optimizer, st['good_generator'], w))]
+        out = []
+        for k, segs in enumerate(phases):
+            for j, (fn, grads) in enumerate(segs):
+                out.append((fn, grads, j == 0 and k > 0))       # a solver run that opens with the previous network's optimiser step
+        return out + [(self._c_apply, None, True)]
 
     # ------------------------------------------------------------------ one iteration
     def feed(self, batch):
         """host feed_dict (:249-263) -> placeholders.  batch keys: z_g,y_g,x_l_c,y_l_c,x_l_d,y_l_d,x_u_d,x_u_c
         (numpy arrays or device Acts)."""
+        dev = []
         for key, ph in (('z_g', self.z_g_ph), ('y_g', self.y_g_ph), ('x_l_c', self.x_l_c_ph), ('y_l_c', self.y_l_c_ph),
                         ('x_l_d', self.x_l_d_ph), ('y_l_d', self.y_l_d_ph), ('x_u_d', self.x_u_d_ph), ('x_u_c', self.x_u_c_ph)):
             if key not in batch:
                 continue
             v = batch[key]
             if isinstance(v, Act):
-                ops.copy_rows(ph.t, 0, v.t, ph.t.numel())
+                dev.append((ph.t, 0, v.t, ph.t.numel()))
             else:
                 a = np.ascontiguousarray(v, np.float32).reshape(-1)
                 assert a.size == ph.t.numel(), (key, a.size, ph.t.numel())
                 ph.t.copy_(torch.from_numpy(a), non_blocking=False)
+        if dev:
+            ops.copy_many(dev)                   # device-resident batch: all placeholders in one launch
 
     def sample_latent(self):
         """z ~ U(-1,1), y ~ onehot(U{0..9}) (:234-239) drawn on the device."""
@@ -250,8 +278,8 @@ class Train(Train_base):
         cx.prep_cache = {}                              # filter layouts stay valid between a network's optimiser steps
         cx.plan_tag = key
         try:
-            for i, (fn, grads, overlap) in enumerate(segs):
-                if grads is None:                           # the classifier's optimiser step: needs every bucket
+            for i, (fn, grads, wait) in enumerate(segs):
+                if wait:                                    # this segment opens with an optimiser step: its network's buckets must be in
                     for wk in pending:
                         tgdist.wait_(wk)
                     pending = []
@@ -260,10 +288,7 @@ class Train(Train_base):
                 else:
                     fn()
                 if grads is not None and tgdist.active():
-                    if overlap:
-                        pending.append(tgdist.allreduce_sum_async_(grads))
-                    else:
-                        tgdist.allreduce_sum_(grads)
+                    pending.append(tgdist.allreduce_sum_async_(grads))
         finally:
             cx.prep_cache = None
         self._warm = True
@@ -279,7 +304,7 @@ class Train(Train_base):
         cx.prep_cache = {}
         cx.plan_tag = key
         try:
-            for i, (fn, _grads, _overlap) in enumerate(segs):
+            for i, (fn, _grads, _wait) in enumerate(segs):
                 if graphs[i] is not None:
                     continue
                 lib.call('tg_graph_begin_capture', cx.stream)

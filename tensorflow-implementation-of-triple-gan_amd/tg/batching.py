@@ -11,9 +11,10 @@ def concat_acts(acts, tag='cat'):
         assert (a.h, a.w, a.c, a.ld) == (a0.h, a0.w, a0.c, a0.ld), "concat_acts: layout mismatch"
     n = sum(a.n for a in acts)
     out = cx.new_act(n, a0.h, a0.w, a0.c, a0.ld, tag=tag)
-    off = 0
+    jobs, off = [], 0
     for a in acts:
         numel = a.rows * a.ld
-        ops.copy_rows(out.t, off, a.t, numel)
+        jobs.append((out.t, off, a.t, numel))
         off += numel
+    ops.copy_many(jobs)                      # one launch for all parts
     return out

@@ -42,6 +42,11 @@ class PrepJob(C.Structure):
                 ("b_pad", C.c_int32)]
 
 
+class CopyJob(C.Structure):
+    """tg_copy_job: one contiguous copy of tg_copy_multi_f32."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64)]
+
+
 class RngJob(C.Structure):
     """tg_rng_job: one random draw of tg_rng_multi_f32."""
     _fields_ = [("out", C.c_void_p), ("n", C.c_int64), ("mode", C.c_int32), ("a", C.c_float), ("b", C.c_float), ("stream_id", C.c_uint32)]

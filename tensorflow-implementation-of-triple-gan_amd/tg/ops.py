@@ -396,9 +396,15 @@ def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_g
 
 # ------------------------------------------------------------------ pointwise / pooling / concat
 
-def scale_mask(x, mask_t, mscale):
-    """y = x*mask*mscale (inverted dropout, Model/modle_base.py:190-191)."""
+def scale_mask(x, mask_t, mscale, defer=False):
+    """y = x*mask*mscale (inverted dropout, Model/modle_base.py:190-191).  defer: return a handle WITHOUT storage whose dropout the next
+    op applies inside its own launch — only cond_concat does (the discriminator's dropout -> concat pairs, Good_GAN_cifar10.py:63-65,
+    73-75); anything else touching the handle fails loudly on its missing buffer."""
     cx = ctx()
+    if defer:
+        y = Act(None, x.n, x.h, x.w, x.c, x.ld, requires_grad=x.requires_grad)
+        y.pending = (x, mask_t, mscale)
+        return y
     y = cx.new_act(x.n, x.h, x.w, x.c, x.ld, requires_grad=x.requires_grad)
     _call('tg_actgrad_f32', x.ptr, x.ld, None, 0, _p(mask_t), x.c, mscale, y.ptr, y.ld, x.rows, x.c, 0, 0.0, cx.stream)
     if cx.tape is not None and x.requires_grad:
@@ -413,12 +419,18 @@ def cond_concat(x, y_onehot_t, ncls):
     """concat([x, y*ones], 3), output channel-padded to 32 (Model/modle_base.py:239-244)."""
     cx = ctx()
     ld = pad32(x.c + ncls)
+    mask_t, mscale = None, 1.0
+    if x.pending is not None:                    # a deferred dropout in front (scale_mask(defer=True)): one launch for both
+        x, mask_t, mscale = x.pending
     out = cx.new_act(x.n, x.h, x.w, x.c + ncls, ld, requires_grad=x.requires_grad)
-    _call('tg_cond_concat_f32', x.ptr, x.ld, x.c, None, 0, 1.0, _p(y_onehot_t), ncls, out.ptr, ld, x.n, x.h * x.w, cx.stream)
+    _call('tg_cond_concat_f32', x.ptr, x.ld, x.c, _p(mask_t), x.c, mscale, _p(y_onehot_t), ncls, out.ptr, ld, x.n, x.h * x.w, cx.stream)
     if cx.tape is not None and x.requires_grad:
         def bwd():   # gradient of the first x.c channels; the label channels are constants
             g = out.grad
-            if x.grad is None and x.strided_grad_ok:
+            if mask_t is not None:
+                gx = cx.grad_of(x)
+                _call('tg_actgrad_f32', g.ptr, g.ld, None, 0, _p(mask_t), x.c, mscale, gx.ptr, gx.ld, x.rows, x.c, 0, 0.0, cx.stream)
+            elif x.grad is None and x.strided_grad_ok:
                 # no copy: x's gradient IS the leading channels of the concatenated gradient (every consumer of an activation
                 # gradient reads it through (pointer, channel stride))
                 x.grad = Act(g.t, x.n, x.h, x.w, x.c, g.ld)
@@ -542,6 +554,16 @@ def copy_rows(dst_t, dst_off, src_t, numel):
     cx = ctx()
     numel = int(numel)
     _call('tg_copy2d_f32', C.c_void_p(src_t.data_ptr()), numel, C.c_void_p(dst_t.data_ptr() + 4 * int(dst_off)), numel, 1, numel, cx.stream)
+
+
+def copy_many(jobs):
+    """[(dst tensor, dst element offset, src tensor, numel)] as contiguous device copies, 16 per launch (tg_copy_multi_f32)."""
+    cx = ctx()
+    jobs = [j for j in jobs if j[3] > 0]
+    for k in range(0, len(jobs), 16):
+        part = jobs[k:k + 16]
+        arr = (lib.CopyJob * len(part))(*[lib.CopyJob(s.data_ptr(), d.data_ptr() + 4 * int(off), int(n)) for d, off, s, n in part])
+        _call('tg_copy_multi_f32', C.cast(arr, C.c_void_p), len(part), cx.stream)
 
 
 def reshape(x, n, h, w, c):

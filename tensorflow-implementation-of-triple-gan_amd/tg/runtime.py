@@ -26,7 +26,7 @@ def pad32(c):
 class Act(object):
     """Handle of an NHWC activation buffer: logical shape [n,h,w,c], channel stride ld >= c
     (channels c..ld are zero when the buffer feeds an MFMA kernel)."""
-    __slots__ = ('t', 'n', 'h', 'w', 'c', 'ld', 'grad', 'requires_grad', 'strided_grad_ok', 'grad_sink', 'grad_fused')
+    __slots__ = ('t', 'n', 'h', 'w', 'c', 'ld', 'grad', 'requires_grad', 'strided_grad_ok', 'grad_sink', 'grad_fused', 'pending')
 
     def __init__(self, t, n, h, w, c, ld, requires_grad=False):
         self.t, self.n, self.h, self.w, self.c, self.ld = t, n, h, w, c, ld
@@ -35,6 +35,8 @@ class Act(object):
         self.strided_grad_ok = False      # set by producers whose backward reads .grad through (pointer, channel stride) only
         self.grad_sink = None             # (act, alpha, seg_rows): the producer is a mean-only-BN layer — a consumer whose input-gradient
         self.grad_fused = None            # launch can apply act'(y) and sum the columns stores t = dx*act'(y) in .grad and the sums here
+        self.pending = None               # (source Act, keep-mask, scale): a dropout the NEXT op applies in its own launch (ops.scale_mask(defer=True));
+                                          # such a handle has no storage of its own (t is None) until that op has run
 
     @property
     def rows(self):
@@ -500,12 +502,13 @@ class Context(object):
         finally:
             self.tape = prev
 
-    def run_tape(self, tape):
-        for fn in reversed(tape):
-            if fn is not BUCKET_BOUNDARY:
-                fn()
-        del tape[:]
-        self.flush_tails()
+    def run_tape(self, tape, stop_at_boundary=False):
+        """run a recorded tape in reverse (all of it, or down to its last bucket boundary: see backward); returns the unexecuted head
+        or None, and empties the tape when everything ran."""
+        rest = self._run_reverse(tape, stop_at_boundary)
+        if rest is None:
+            del tape[:]
+        return rest
 
     @contextlib.contextmanager
     def variable_scope(self, name):
@@ -569,29 +572,35 @@ class Context(object):
         if self.tape is not None:
             self.tape.append(fn)
 
-    def grad_bucket_boundary(self):
+    def grad_bucket_boundary(self, net=None):
         """Called by a model between two layers of its forward pass: once the backward pass has come back to this point, the
-        variable gradients of every layer recorded AFTER it are final (data-parallel bucket boundary)."""
+        variable gradients of every layer of network `net` recorded AFTER it are final (data-parallel bucket boundary)."""
         if self.tape is not None:
-            self.tape.append(BUCKET_BOUNDARY)
+            self.tape.append(_Boundary(net))
 
-    def backward(self, stop_at_boundary=False):
-        """Run the recorded closures in reverse.  stop_at_boundary: stop at the last grad_bucket_boundary() mark and return the
-        not-yet-executed head of the tape (run it later with run_tape inside phase_scope(..., counter=self.counter)), so that
-        the finished bucket can be all-reduced while the rest of the backward pass runs; None when everything ran."""
-        tape, self.tape = self.tape, []
+    def _run_reverse(self, tape, stop_at_boundary):
         i = len(tape)
         while i > 0:
             i -= 1
             fn = tape[i]
-            if fn is BUCKET_BOUNDARY:
-                if stop_at_boundary:
+            if isinstance(fn, _Boundary):
+                # stop_at_boundary: True = at any mark, a network name = at that network's marks only (a solver run's tape also
+                # carries the marks of the networks it merely applies)
+                if stop_at_boundary is True or (stop_at_boundary and fn.net == stop_at_boundary):
                     self.flush_tails()             # the finished bucket's gradients must be complete
                     return tape[:i]
                 continue
             fn()
         self.flush_tails()
         return None
+
+    def backward(self, stop_at_boundary=False):
+        """Run the recorded closures in reverse.  stop_at_boundary: stop at the last grad_bucket_boundary() mark and return the
+        not-yet-executed head of the tape (continue with run_tape(head, stop_at_boundary=...) inside phase_scope(..., counter=
+        self.counter) — once per remaining boundary), so that every finished bucket can be all-reduced while the rest of the backward
+        pass runs; None when everything ran."""
+        tape, self.tape = self.tape, []
+        return self._run_reverse(tape, stop_at_boundary)
 
     def flush_tails(self):
         """launch the deferred filter-gradient tails (slab reduction, weight-norm gradient) of the layers whose wgrad has been
@@ -605,7 +614,15 @@ class Context(object):
             lib.call('tg_filter_grad_tail_multi_f32', C.cast(arr, C.c_void_p), len(part), self.stream)
 
 
-BUCKET_BOUNDARY = object()
+class _Boundary(object):
+    """tape entry of Context.grad_bucket_boundary."""
+    __slots__ = ('net',)
+
+    def __init__(self, net=None):
+        self.net = net
+
+
+BUCKET_BOUNDARY = _Boundary
 
 
 _CTX = None

@@ -10,7 +10,7 @@ tg.dist is replaced by an emulation of the RCCL process group's stream semantics
 
 Adam applies grad / world = (2 g) / 2 = g exactly, so every result must equal the plain single-process run BIT FOR BIT — unless
 a consumer ran before the exchange finished (it would see g instead of 2 g) or the exchange started before the gradients were final.
-Runs with hipGraph segments (the bucketed classifier exchange beside a graph launch) and eagerly."""
+Runs with hipGraph segments (every bucket's exchange beside the graph launch of the next backward segment) and eagerly."""
 import numpy as np
 import pytest
 
@@ -94,8 +94,10 @@ def test_exchange_is_ordered_against_producers_and_consumers(graph, monkeypatch)
     tr, l_dp, p_dp = run(graph)
     torch.cuda.synchronize()
     assert tr.world == 2
-    # per iteration: grad D, grad G, the classifier's first bucket synchronously; its large bucket asynchronously
-    assert ex.calls['asynchronous'] == 4 and ex.calls['sync'] == 12 and ex.calls['waits'] == 16, ex.calls
+    # per iteration every gradient bucket goes out asynchronously behind the segment that completes it — discriminator 3 (one per
+    # resolution stage), generator 2 (gg_dconv0 ... first), classifier 2 — and is waited for by the segment that applies the optimiser step
+    assert ex.calls['asynchronous'] == 4 * 7 and ex.calls['sync'] == 0 and ex.calls['waits'] == 4 * 7, ex.calls
+    assert len(tr._segments()) == 8 and [w for _, _, w in tr._segments()] == [False, False, False, True, False, True, False, True]
     assert l_dp == l_ref
     for k in p_ref:
         np.testing.assert_array_equal(p_dp[k], p_ref[k], err_msg=k)
