@@ -17,6 +17,7 @@
 //     barrier per K-step (a K-step is 1024 matrix-pipe cycles per SIMD).
 // Numerics: every MFMA operand is rounded to bf16 (RNE) exactly as the generic tg_*_bf16 kernels do, products accumulate in fp32 —
 // the results differ from those kernels only by the order of the fp32 accumulation (channel chunks outermost here).
+#include <cstdlib>
 #include "tg_common.h"
 #include "tg_device.h"
 #include "tg_conv3x3_bf16.h"
@@ -56,11 +57,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-__device__ __forceinline__ u32x2 pack4(u32x4 v) {             // 4 fp32 -> 4 bf16 (RNE), 8 bytes
-  bf16x4 b;
-  b[0] = (__bf16)__builtin_bit_cast(float, v.x); b[1] = (__bf16)__builtin_bit_cast(float, v.y);
-  b[2] = (__bf16)__builtin_bit_cast(float, v.z); b[3] = (__bf16)__builtin_bit_cast(float, v.w);
-  return __builtin_bit_cast(u32x2, b);
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack2(uint32_t a, uint32_t b) {   // 2 fp32 -> 2 bf16 (RNE): one v_cvt_pk_bf16_f32
+  const f32x2 f = {__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
+}
+
+__device__ __forceinline__ u32x2 pack4(u32x4 v) {             // 4 fp32 -> 4 bf16 (RNE), 8 bytes, channel order kept
+  u32x2 r;
+  r.x = pack2(v.x, v.y);
+  r.y = pack2(v.z, v.w);
+  return r;
 }
 
 // LDS byte offset of 16-B chunk `chunk` (8 bf16) of row `row`: 128-B rows, chunk index XOR-swizzled with bits 1..3 of the row.
@@ -73,7 +82,7 @@ __global__ void __launch_bounds__(THREADS, 2) conv3x3_bf16_kernel(ConvParams p) 
   constexpr int A_BYTES = (HP * 128 + 255) / 256 * 256, B_BYTES = BN * 128;
   constexpr int A_UNITS = HP * 16, A_IT = (A_UNITS + THREADS - 1) / THREADS;   // 16-B fp32 loads of one halo chunk, per thread
   constexpr int B_IT = BN * 16 / THREADS;                                      // = 4
-  constexpr int EPI_BYTES = COLSUM ? (128 * (BN + 4) * 4 + 2 * (THREADS / BN) * BN * 4) : 0;
+  constexpr int EPI_BYTES = 128 * (BN + 4) * 4 + 2 * (THREADS / BN) * BN * 4;
   constexpr int MAIN_BYTES = 2 * A_BYTES + 2 * B_BYTES;
   constexpr int SMEM = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + BM * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
@@ -204,8 +213,7 @@ __global__ void __launch_bounds__(THREADS, 2) conv3x3_bf16_kernel(ConvParams p) 
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
-            if (COLSUM) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);   // D[pixel][channel]: lane = channel
-            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);        // D[channel][pixel]: lane = pixel
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);   // D[pixel][channel]: lane = channel
       }
       if (more) sstore_b(bbuf ^ 1);
       if (t == 8 && more_c) sstore_a((c + 1) & 1);
@@ -215,50 +223,69 @@ __global__ void __launch_bounds__(THREADS, 2) conv3x3_bf16_kernel(ConvParams p) 
   }
 
   // ---- epilogue (the operand tiles are dead; t_out lies behind them) ---------------------------------------------------------------
+  // The tile leaves through LDS row-wise in two passes of 128 rows (67 KB each): a lane of the accumulator holds ONE channel and 16
+  // pixels, so storing from registers would scatter dwords; from LDS every thread moves 16-B pieces of pixel rows — coalesced stores,
+  // coalesced loads of the activation for the actsum form — with bias + activation applied on the way (plain form) or, for the
+  // mean-only-BN forms (tg_igemm_colsum_bf16 / tg_igemm_actsum_bf16), the per-application column sums taken from LDS as well.  A tile
+  // lies inside ONE image, hence inside one application segment.
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  constexpr int TLD = BN + 4, PARTS = THREADS / BN;
+  float* tile = reinterpret_cast<float*>(smem);
+  float* red = tile + 128 * TLD;
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ymul ? p.ymul : p.out), 0, p.out_bytes, 0x00020000);
+  int seg = 0;
   if (COLSUM) {
-    // mean-only-BN variants (tg_igemm_colsum_bf16 / tg_igemm_actsum_bf16): the tile leaves through LDS row-wise (16-B pieces of pixel
-    // rows: coalesced stores, coalesced loads of the activation for the actsum form) and the per-application column sums are taken
-    // from LDS.  A tile lies inside ONE image, hence inside one application segment.  Two passes of 128 rows (67 KB of LDS each).
-    constexpr int TLD = BN + 4, PARTS = THREADS / BN;
-    float* tile = reinterpret_cast<float*>(smem);
-    float* red = tile + 128 * TLD;
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ymul ? p.ymul : p.out), 0, p.out_bytes, 0x00020000);
     const int m0 = mt * BM;
-    int seg = 0, acc_rows = p.seg_rows[0];
+    int acc_rows = p.seg_rows[0];
     while (seg < p.nseg - 1 && m0 >= acc_rows) acc_rows += p.seg_rows[++seg];
-    const bool ym = p.ymul != nullptr;
-    float csum = 0.f;
-    for (int pass = 0; pass < 2; ++pass) {
-      if ((wm >> 1) == pass) {
+  }
+  const bool ym = COLSUM && p.ymul != nullptr;
+  float csum = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    if ((wm >> 1) == pass) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              tile[((wm & 1) * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * TLD + wn0 + ni * 32 + col] = acc[mi][ni][r];
-      }
-      __syncthreads();
-      constexpr int G4 = BN / 4;
-      for (int i = tid; i < 128 * G4; i += THREADS) {
-        const int rl = i / G4, cg = i - rl * G4;
-        const int n = n0 + cg * 4;
-        const uint32_t off = n >= p.n_store ? OOB : t_out[pass * 128 + rl] + (uint32_t)n * 4u;
-        const float4 tv = *reinterpret_cast<const float4*>(tile + rl * TLD + cg * 4);
-        float va[4] = {tv.x, tv.y, tv.z, tv.w};
-        if (ym) {
-          const u32x4 yb = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
-          va[0] *= tgd::act_grad(__builtin_bit_cast(float, yb.x), p.ymul_act, p.ymul_alpha);
-          va[1] *= tgd::act_grad(__builtin_bit_cast(float, yb.y), p.ymul_act, p.ymul_alpha);
-          va[2] *= tgd::act_grad(__builtin_bit_cast(float, yb.z), p.ymul_act, p.ymul_alpha);
-          va[3] *= tgd::act_grad(__builtin_bit_cast(float, yb.w), p.ymul_act, p.ymul_alpha);
-          *reinterpret_cast<float4*>(tile + rl * TLD + cg * 4) = make_float4(va[0], va[1], va[2], va[3]);
+          for (int r = 0; r < 16; ++r)
+            tile[((wm & 1) * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * TLD + wn0 + ni * 32 + col] = acc[mi][ni][r];
+    }
+    __syncthreads();
+    constexpr int G4 = BN / 4;
+    for (int i = tid; i < 128 * G4; i += THREADS) {
+      const int rl = i / G4, cg = i - rl * G4;
+      const int n = n0 + cg * 4;
+      const uint32_t off = n >= p.n_store ? OOB : t_out[pass * 128 + rl] + (uint32_t)n * 4u;
+      const float4 tv = *reinterpret_cast<const float4*>(tile + rl * TLD + cg * 4);
+      float va[4] = {tv.x, tv.y, tv.z, tv.w};
+      if (!COLSUM) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (p.bias != nullptr && n + e < p.n_store) va[e] += p.bias[n + e];
+          va[e] = tgd::act(va[e], p.act, p.alpha);
         }
+      } else if (ym) {      // input gradient times the activation derivative of the layer that produced this conv's input
+        const u32x4 yb = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
+        // (elements copied to scalars first: __builtin_bit_cast applied to a vector-element expression reads element 0 — hipcc, ROCm 7.2)
+        const uint32_t y0 = yb.x, y1 = yb.y, y2 = yb.z, y3 = yb.w;
+        va[0] *= tgd::act_grad(__builtin_bit_cast(float, y0), p.ymul_act, p.ymul_alpha);
+        va[1] *= tgd::act_grad(__builtin_bit_cast(float, y1), p.ymul_act, p.ymul_alpha);
+        va[2] *= tgd::act_grad(__builtin_bit_cast(float, y2), p.ymul_act, p.ymul_alpha);
+        va[3] *= tgd::act_grad(__builtin_bit_cast(float, y3), p.ymul_act, p.ymul_alpha);
+        *reinterpret_cast<float4*>(tile + rl * TLD + cg * 4) = make_float4(va[0], va[1], va[2], va[3]);
+      }
+      if ((p.n_store & 3) == 0) {
         const u32x4 pk = {__builtin_bit_cast(uint32_t, va[0]), __builtin_bit_cast(uint32_t, va[1]), __builtin_bit_cast(uint32_t, va[2]),
                           __builtin_bit_cast(uint32_t, va[3])};
         __builtin_amdgcn_raw_buffer_store_b128(pk, rs_o, off, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, va[e]), rs_o, n + e >= p.n_store ? OOB : off + 4u * e, 0, 0);
       }
+    }
+    if (COLSUM) {
       if (ym) __syncthreads();
       {
         const int c = tid % BN, q = tid / BN;
@@ -271,42 +298,10 @@ __global__ void __launch_bounds__(THREADS, 2) conv3x3_bf16_kernel(ConvParams p) 
 #pragma unroll
         for (int q = 0; q < PARTS; ++q) csum += red[q * BN + tid];
       }
-      __syncthreads();                                        // the tile is rewritten by the second pass
     }
-    if (tid < BN && n0 + tid < p.n_store) atomicAdd(p.colsum + (int64_t)seg * p.c_out + n0 + tid, (double)csum);
-    return;
+    __syncthreads();                                          // the tile is rewritten by the second pass
   }
-  __syncthreads();                                            // t_out (written before the K loop) is visible; nothing else to wait for
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const uint32_t ro = t_out[wm0 + mi * 32 + col];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn0 + ni * 32 + 8 * q + 4 * half;
-        float va[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = acc[mi][ni][4 * q + e];
-          if (p.bias != nullptr && n + e < p.n_store) t += p.bias[n + e];
-          va[e] = tgd::act(t, p.act, p.alpha);
-        }
-        if ((p.n_store & 3) == 0) {
-          const uint32_t off = n >= p.n_store ? OOB : ro + (uint32_t)n * 4u;
-          const u32x4 pk = {__builtin_bit_cast(uint32_t, va[0]), __builtin_bit_cast(uint32_t, va[1]), __builtin_bit_cast(uint32_t, va[2]),
-                            __builtin_bit_cast(uint32_t, va[3])};
-          __builtin_amdgcn_raw_buffer_store_b128(pk, rs_o, off, 0, 0);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t off = n + e >= p.n_store ? OOB : ro + (uint32_t)(n + e) * 4u;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, va[e]), rs_o, off, 0, 0);
-          }
-        }
-      }
-    }
-  }
+  if (COLSUM && tid < BN && n0 + tid < p.n_store) atomicAdd(p.colsum + (int64_t)seg * p.c_out + n0 + tid, (double)csum);
 }
 
 template <int W>

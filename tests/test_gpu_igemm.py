@@ -51,6 +51,11 @@ CONV_CASES = [  # n,h,w,cin,cout,k,stride,pad
     (7, 9, 7, 40, 32, 3, 2, 'SAME'),        # ragged sizes, M not a tile multiple
     (3, 8, 8, 138, 138, 3, 1, 'SAME'),      # 160 padded channels both ways: 64-wide tiles whose last one overhangs (columns and reduction rows)
     (2, 16, 16, 266, 96, 3, 2, 'SAME'),     # 288 = 4.5 x 64 reduction channels, 96 = 1.5 x 64 columns
+    # classifier-shaped 3x3 layers: with bf16 operands the forward pass and the input gradient take the halo-tiled kernel
+    # (csrc/conv3x3_bf16.hip: widths 16 / 32 / 64, 64 | channels in, 128 | channels out)
+    (3, 32, 32, 128, 128, 3, 1, 'SAME'),
+    (2, 16, 16, 128, 256, 3, 1, 'SAME'),
+    (1, 64, 64, 64, 128, 3, 1, 'SAME'),
 ]
 
 

@@ -190,7 +190,9 @@ def test_philox_streams_are_distinct_and_well_distributed():
     assert (o.sum(1) == 1).all() and o.sum(0).min() > 50
 
 
-@pytest.mark.parametrize("segs,h", [([2, 4, 1], 8), ([5, 5, 9], 6)])      # 64-pixel images (aligned) and 36-pixel ones (ragged: tiles straddle applications)
+# 64-pixel images (aligned), 36-pixel ones (ragged: tiles straddle applications), and 16x16 / 32x32 ones: with bf16 operands those take
+# the halo-tiled 3x3 kernel (csrc/conv3x3_bf16.hip: 256-pixel tiles of whole image rows)
+@pytest.mark.parametrize("segs,h", [([2, 4, 1], 8), ([5, 5, 9], 6), ([2, 3, 1], 16), ([1, 2], 32)])
 @pytest.mark.parametrize("prec", ['f32', 'bf16'])
 def test_fused_mean_only_batch_norm_forward_backward(prec, segs, h):
     """tg_igemm_colsum_{f32,bf16} + tg_mobn_apply_f32 (training and evaluation) and tg_mobn_bwd_f32 against the oracle's
@@ -346,15 +348,15 @@ def test_actgrad_with_bias_gradient(rows, c, ld_out, act):
 
 
 @pytest.mark.parametrize("prec", ['f32', 'bf16'])
-@pytest.mark.parametrize("segs,h", [([2, 4, 1], 8), ([5, 5, 9], 6)])
-def test_input_gradient_fused_with_mobn_backward_statistics(prec, segs, h):
+@pytest.mark.parametrize("segs,h,cin,cout", [([2, 4, 1], 8, 64, 96), ([5, 5, 9], 6, 64, 96), ([2, 1, 3], 16, 128, 256), ([1, 2], 32, 128, 128)])
+def test_input_gradient_fused_with_mobn_backward_statistics(prec, segs, h, cin, cout):
     """tg_igemm_actsum_* (input gradient of a conv, times act'(y) of the mean-only-BN layer that produced its input, with per-application
     column sums) + tg_mobn_center_f32 == conv2d_bwd_input -> lrelu' -> mean_only_batch_norm backward of the oracle."""
     from tg import geom
     lib = _lib()
     q = (lambda a: T.bf16_round(a)) if prec == 'bf16' else (lambda a: a)
     rng = np.random.default_rng(9)
-    n, w_, cin, cout = sum(segs), h, 64, 96           # the differentiated conv: cin -> cout; its input is the MOBN layer's output y
+    n, w_ = sum(segs), h                              # the differentiated conv: cin -> cout; its input is the MOBN layer's output y
     y = rng.standard_normal((n, h, w_, cin)).astype(np.float32)          # activated output of the producing layer (sign decides lrelu')
     wt = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
     dpre = rng.standard_normal((n, h, w_, cout)).astype(np.float32)      # gradient at the conv's pre-activation

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""bf16 MFMA conv path on the classifier's 3x3 layers (BASELINE.json configs[3]): TFLOP/s of tg_igemm_bf16 / tg_igemm_colsum_bf16 (halo-tiled
+kernel, csrc/conv3x3_bf16.hip) against the generic bf16 implicit GEMM (TG_NO_CONV3X3_BF16=1) and the fp32 kernel, on standard-normal
+operands, N = 250 images.  Prints one JSON line per layer; peak = 2 500 TFLOP/s dense bf16 (MI355X_MICROARCH.md)."""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tensorflow-implementation-of-triple-gan_amd"))
+import torch  # noqa: E402
+from tg import geom, lib  # noqa: E402
+
+PEAK_BF16 = 2500.0
+N = int(os.environ.get('TG_BENCH_N', '250'))
+LAYERS = [('conv1_2', 32, 128, 128), ('conv2_1', 16, 128, 256), ('conv2_2', 16, 256, 256)]
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+lib.load()
+st = lib.cur_stream()
+for name, hw, ci, co in LAYERS:
+    x = torch.randn(N, hw, hw, ci, device='cuda')
+    w = torch.randn(co, 9, ci, device='cuda') * 0.05
+    y = torch.empty(N, hw, hw, co, device='cuda')
+    sums = torch.zeros(2 * co, dtype=torch.float32, device='cuda')
+    d = geom.conv_fwd(N, hw, hw, ci, co, 3, 1, 'SAME', act='lrelu')
+    dc = geom.conv_fwd(N, hw, hw, ci, co, 3, 1, 'SAME')
+    seg = (C.c_int32 * 1)(N * hw * hw)
+    gf = 2.0 * N * hw * hw * 9 * ci * co / 1e9
+    out = dict(layer=name, gflop=round(gf, 1))
+    for tag, fn in (('bf16', lambda: lib.call('tg_igemm_bf16', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st)),
+                    ('bf16_colsum', lambda: lib.call('tg_igemm_colsum_bf16', dc, lib.ptr(x), lib.ptr(w), lib.ptr(y), seg, 1, lib.ptr(sums), 0, st)),
+                    ('f32', lambda: lib.call('tg_igemm_f32', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st))):
+        ms = timeit(fn)
+        out[tag] = dict(ms=round(ms, 4), tflops=round(gf / ms, 1), frac_of_bf16_peak=round(gf / ms / PEAK_BF16, 4) if tag != 'f32' else None)
+    print(json.dumps(out), flush=True)
