@@ -9,9 +9,8 @@
 
 Runs the D+G+C step on synthetic images already resident in HBM, then one instrumented eager iteration with
 per-kernel-class HIP-event timing.  Prints ONE JSON line: ms/step, images/sec and, per kernel class, launches,
-milliseconds, executed GFLOP or algorithmic GB and the resulting TFLOP/s or GB/s against the MI355X peaks
-(fp32 MFMA 157.3 TFLOP/s — the bf16 rows are quoted against the same figure, i.e. as a speed-up over the fp32 roofline —
-and 8 TB/s HBM).
+milliseconds, executed GFLOP or algorithmic GB and the resulting TFLOP/s or GB/s against the MI355X peaks of the arithmetic the
+launches use (fp32 MFMA 157.3 TFLOP/s; bf16 MFMA 2 500 TFLOP/s dense for the *-bf16 configurations — MI355X_MICROARCH.md) and 8 TB/s HBM.
 """
 import argparse
 import ctypes as C
@@ -28,7 +27,7 @@ for p in (ROOT, PKG):
 
 import numpy as np  # noqa: E402
 
-PEAK_TF, PEAK_GBS = 157.3, 8000.0
+PEAK_TF, PEAK_TF_BF16, PEAK_GBS = 157.3, 2500.0, 8000.0
 
 
 SHAPES = {   # name: (data, H, C, B_G, L_C, U_C, L_D, U_D, mfma dtype, lambda_1, lr, cla_lr)
@@ -134,7 +133,9 @@ def main():
             continue
         e = dict(launches=n.value, ms=round(ms.value, 3))
         if f.value > 0:
-            e.update(gflop=round(f.value / 1e9, 1), tflops=round(f.value / ms.value / 1e9, 1), frac_of_mfma_peak=round(f.value / ms.value / 1e9 / PEAK_TF, 3))
+            peak = PEAK_TF_BF16 if cfg.MFMA_DTYPE == 'bf16' else PEAK_TF             # the MFMA classes run in the configuration's operand type
+            e.update(gflop=round(f.value / 1e9, 1), tflops=round(f.value / ms.value / 1e9, 1), frac_of_mfma_peak=round(f.value / ms.value / 1e9 / peak, 4),
+                     mfma_peak_tflops=peak)
         if b.value > 0:
             e.update(gbytes=round(b.value / 1e9, 2), gb_per_s=round(b.value / ms.value / 1e6, 0), frac_of_hbm_peak=round(b.value / ms.value / 1e6 / PEAK_GBS, 3))
         classes[name] = e

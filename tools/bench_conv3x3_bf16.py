@@ -42,9 +42,12 @@ for name, hw, ci, co in LAYERS:
     seg = (C.c_int32 * 1)(N * hw * hw)
     gf = 2.0 * N * hw * hw * 9 * ci * co / 1e9
     out = dict(layer=name, gflop=round(gf, 1))
+    only = os.environ.get('TG_BENCH_ONLY')
     for tag, fn in (('bf16', lambda: lib.call('tg_igemm_bf16', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st)),
                     ('bf16_colsum', lambda: lib.call('tg_igemm_colsum_bf16', dc, lib.ptr(x), lib.ptr(w), lib.ptr(y), seg, 1, lib.ptr(sums), 0, st)),
                     ('f32', lambda: lib.call('tg_igemm_f32', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st))):
+        if only and tag != only:
+            continue
         ms = timeit(fn)
         out[tag] = dict(ms=round(ms, 4), tflops=round(gf / ms, 1), frac_of_bf16_peak=round(gf / ms / PEAK_BF16, 4) if tag != 'f32' else None)
     print(json.dumps(out), flush=True)
