@@ -169,6 +169,14 @@ int64_t tg_filter_workspace_bytes(int n_taps, int c_in_pad, int c_out_pad);
 int tg_igemm_tile(const tg_igemm_desc* descs, int n_desc, const int32_t* seg_rows, int nseg, int bf16, int32_t* bm_out, int32_t* bn_out);
 int tg_igemm_colsum_supported(const tg_igemm_desc* d, const int32_t* seg_rows, int nseg);
 
+/* The halo-tiled 3x3 / stride-1 / SAME kernel (csrc/conv3x3_bf16.hip) behind tg_igemm_{f32,bf16} and tg_igemm_colsum_{f32,bf16}:
+ * one 256-pixel tile of whole image rows per workgroup, the halo loaded once for the nine taps.  policy 0 (default): taken where the
+ * layer applies AND the launch fills the chip's rounds of one workgroup per CU well enough to beat the generic implicit GEMM;
+ * 1: wherever the layer applies (kernel tests); 2: never (A/B).  Returns the previous policy; any other argument only queries.
+ * tg_conv3x3_launches: launches of that kernel since the library was loaded. */
+int tg_conv3x3_policy(int policy);
+int64_t tg_conv3x3_launches(void);
+
 /* ---- parameter-side kernels ---------------------------------------------------------------------- */
 /* scale[c] = g[c] * rsqrt(max(sum_r V[r][c]^2, 1e-12)), V row-major [rows][c].
  * tf.nn.l2_normalize(V,[0,1,2])*g of conv2d_WN (Model/nn.py:502) and g/sqrt(sum V^2) of dense_WN (nn.py:554). */

@@ -24,6 +24,7 @@
 #include "tg_conv3x3_bf16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -75,6 +76,7 @@ struct ConvParams {
   int tap[9];                                  // (tapw << 16) | ((dy & 0xff) << 8) | (dx & 0xff)
   int n_tiles_m, n_tiles_n;
   uint32_t in_bytes, w_bytes, out_bytes;
+  int f32;                                     // 1: exact-fp32 operands (conv3x3_ws_kernel<..., BF16 = false>)
   int stagger;                                 // first-round delay (in units of ~1k cycles) of every second workgroup slot: see the kernel
   int dbg;                                     // TG_CONV3X3_DBG (diagnostic timing only, results then wrong): 1 no stores, 2 no filter loads in the loop, 4 no MFMAs, 8 no halo reload
 };
@@ -381,12 +383,19 @@ __global__ void __launch_bounds__(2 * BM, 2) conv3x3_bf16_kernel(ConvParams p) {
 // lockstep, so the matrix pipe idles whenever they issue loads, convert, write LDS or wait at the barrier (stamped: 3.0 k of every
 // 7.0 k cycles); here the pipe's wave only ever waits at the one barrier per step.  Both roles execute the same barriers.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int W, bool COLSUM>
-__global__ void __launch_bounds__(512, 2) conv3x3_bf16_ws_kernel(ConvParams p) {
+// BF16 = false: the SAME structure on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32) for the fp32 training step — fp32 LDS
+// images of 32 channels per chunk (the same 128-B rows and swizzle), one ds_read_b128 feeding four k-steps of both operands (lane half h
+// of k-group g supplies k = 8g + 4h + s in step s), no conversion.  At 1/16 of the bf16 matrix rate a three-tap step is 24.6 k matrix-pipe
+// cycles per consumer, so the loaders' work and the prologue / epilogue weigh a sixteenth of what they do above.
+template <int W, bool COLSUM, bool BF16>
+__global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvParams p) {
   constexpr int BM = 256, THREADS = 512, TPS = 3, NG = 3;
+  constexpr int KCH = BF16 ? 64 : 32;                                  // channels per chunk: 128 B of LDS per pixel either way
+  constexpr int UPR = BF16 ? 16 : 8;                                   // 16-B global loads (4 fp32) per row and chunk
+  constexpr int RPP = 256 / UPR;                                       // rows per staging pass of the 256 loader threads
   constexpr int R = BM / W, HW_ = W + 2, HP = (R + 2) * HW_;
   constexpr int A_BYTES = (HP * 128 + 255) / 256 * 256, B_TAP = BN * 128, B_BYTES = TPS * B_TAP;
-  constexpr int A_IT = (HP + 15) / 16, B_IT = BN / 16;                 // 256 loader threads: 16 rows per staging pass
+  constexpr int A_IT = (HP + RPP - 1) / RPP, B_IT = BN / RPP;
   constexpr int EPI_BYTES = 128 * (BN + 4) * 4 + (THREADS / BN) * BN * 4;
   constexpr int MAIN_BYTES = A_BYTES + 2 * B_BYTES;
   constexpr int SMEM = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + BM * 4;
@@ -406,7 +415,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_bf16_ws_kernel(ConvParams p) {
     const int ty = tid / W, tx = tid - ty * W;
     t_out[tid] = (uint32_t)(((img * p.h + row0 + ty) * W + tx) * p.ld_out) * 4u;
   }
-  const int nchunks = p.ld_in / KC;
+  const int nchunks = p.ld_in / KCH;
   const int half = lane >> 5, col = lane & 31;
   f32x16 acc[2][4];
 
@@ -415,29 +424,34 @@ __global__ void __launch_bounds__(512, 2) conv3x3_bf16_ws_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
     const int lt = tid - 256;
-    const int q16 = lt & 15, row_t = lt >> 4;
-    const int st_lds = lds_off(row_t, q16 >> 1) + (q16 & 1) * 8;       // rows advance by 16 per pass: the swizzle term stays
+    const int qu = lt % UPR, row_t = lt / UPR;
+    // rows advance by RPP (16 or 32) per pass: the swizzle term, bits 1..3 of the row, stays
+    const int st_lds = BF16 ? lds_off(row_t, qu >> 1) + (qu & 1) * 8 : lds_off(row_t, qu);
     uint32_t a_voff[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int hp = row_t + 16 * i;
+      const int hp = row_t + RPP * i;
       const int hy = hp / HW_, hx = hp - hy * HW_;
       const int iy = row0 + hy - 1, ix = hx - 1;
       const bool ok = hp < HP && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)W;
-      a_voff[i] = ok ? (uint32_t)(((img * p.h + iy) * W + ix) * p.ld_in + 4 * q16) * 4u : OOB;
+      a_voff[i] = ok ? (uint32_t)(((img * p.h + iy) * W + ix) * p.ld_in + 4 * qu) * 4u : OOB;
     }
-    const uint32_t b_voff = (uint32_t)(((int64_t)(n0 + row_t) * p.w_sn + 4 * q16) * 4);
-    const uint32_t b_pass = (uint32_t)(16 * p.w_sn * 4);
+    const uint32_t b_voff = (uint32_t)(((int64_t)(n0 + row_t) * p.w_sn + 4 * qu) * 4);
+    const uint32_t b_pass = (uint32_t)(RPP * p.w_sn * 4);
     u32x4 ra[A_IT], rb[TPS * B_IT];
     auto gload_a = [&](int c0) {
       const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(c0 * 4);
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_voff[i], so, 0);
     };
+    auto put = [&](unsigned char* dst, u32x4 v) {
+      if constexpr (BF16) *reinterpret_cast<u32x2*>(dst) = pack4(v);
+      else *reinterpret_cast<u32x4*>(dst) = v;
+    };
     auto sstore_a = [&]() {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i)
-        if (i + 1 < A_IT || row_t + 16 * i < HP) *reinterpret_cast<u32x2*>(As + st_lds + i * 16 * 128) = pack4(ra[i]);
+        if (i + 1 < A_IT || row_t + RPP * i < HP) put(As + st_lds + i * RPP * 128, ra[i]);
     };
     auto gload_b = [&](int g, int c0) {
 #pragma unroll
@@ -452,7 +466,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_bf16_ws_kernel(ConvParams p) {
 #pragma unroll
       for (int k = 0; k < TPS; ++k)
 #pragma unroll
-        for (int j = 0; j < B_IT; ++j) *reinterpret_cast<u32x2*>(b + k * B_TAP + j * 16 * 128) = pack4(rb[k * B_IT + j]);
+        for (int j = 0; j < B_IT; ++j) put(b + k * B_TAP + j * RPP * 128, rb[k * B_IT + j]);
     };
     gload_a(0);
     gload_b(0, 0);
@@ -466,8 +480,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_bf16_ws_kernel(ConvParams p) {
       for (int g = 0; g < NG; ++g) {
         const bool more = g < NG - 1 || more_c;
         if (more) {
-          gload_b(g < NG - 1 ? g + 1 : 0, g < NG - 1 ? c * KC : (c + 1) * KC);
-          if (g == 1 && more_c) gload_a((c + 1) * KC);
+          gload_b(g < NG - 1 ? g + 1 : 0, g < NG - 1 ? c * KCH : (c + 1) * KCH);
+          if (g == 1 && more_c) gload_a((c + 1) * KCH);
           sstore_b(bbuf ^ 1);                                   // the other filter buffer: last read one step ago
         }
         __syncthreads();                                        // (S) the consumers are done with this step
@@ -488,7 +502,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_bf16_ws_kernel(ConvParams p) {
       const int ty = r / W, tx = r - ty * W;
       a_hp[mi] = (ty + 1) * HW_ + tx + 1;
     }
-    int b_off[4];                                               // filter row of fragment ni, chunk `half` of k16-step 0; steps add (2s ^ ...) below
+    int b_off[4];                                               // filter row of fragment ni (its chunk is XOR-ed in below)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) b_off[ni] = (ni * 32 + col) * 128;
     const int b_swz = (col >> 1) & 7;                           // rows ni*32 + col: bits 1..3 are col's
@@ -517,17 +531,32 @@ __global__ void __launch_bounds__(512, 2) conv3x3_bf16_ws_kernel(ConvParams p) {
             a_swz[mi] = (hp >> 1) & 7;
           }
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            bf16x8 a[2], b[4];
+          for (int s = 0; s < 4; ++s) {                          // 16-B chunk pair (2s, 2s+1) of the 128-B rows: lane half h takes chunk 2s + h
+            if constexpr (BF16) {
+              bf16x8 a[2], b[4];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(As + a_row[mi] + (((2 * s + half) ^ a_swz[mi]) << 4));
+              for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(As + a_row[mi] + (((2 * s + half) ^ a_swz[mi]) << 4));
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(B + k * B_TAP + b_off[ni] + (((2 * s + half) ^ b_swz) << 4));
+              for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(B + k * B_TAP + b_off[ni] + (((2 * s + half) ^ b_swz) << 4));
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+              for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-              for (int ni = 0; ni < 4; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);   // D[pixel][channel]: lane = channel
+                for (int ni = 0; ni < 4; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);   // D[pixel][channel]: lane = channel
+            } else {
+              f32x4 a[2], b[4];
+#pragma unroll
+              for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(As + a_row[mi] + (((2 * s + half) ^ a_swz[mi]) << 4));
+#pragma unroll
+              for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(B + k * B_TAP + b_off[ni] + (((2 * s + half) ^ b_swz) << 4));
+#pragma unroll
+              for (int e = 0; e < 4; ++e)                        // k = 8s + 4h + e for both operands
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                  for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
+            }
           }
         }
         __syncthreads();                                        // (S)
@@ -618,8 +647,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_bf16_ws_kernel(ConvParams p) {
 template <int W>
 void launch_ws(ConvParams& p, hipStream_t s) {
   const dim3 grid(p.n_tiles_m * p.n_tiles_n);
-  if (p.colsum) hipLaunchKernelGGL((conv3x3_bf16_ws_kernel<W, true>), grid, dim3(512), 0, s, p);
-  else hipLaunchKernelGGL((conv3x3_bf16_ws_kernel<W, false>), grid, dim3(512), 0, s, p);
+  if (p.f32) {
+    if (p.colsum) hipLaunchKernelGGL((conv3x3_ws_kernel<W, true, false>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_ws_kernel<W, false, false>), grid, dim3(512), 0, s, p);
+  } else {
+    if (p.colsum) hipLaunchKernelGGL((conv3x3_ws_kernel<W, true, true>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_ws_kernel<W, false, true>), grid, dim3(512), 0, s, p);
+  }
 }
 
 template <int W, int BM, int TPS>
@@ -634,7 +668,16 @@ void launch(ConvParams& p, hipStream_t s) {
 int g_force_bm = 0, g_dbg = 0, g_stagger = 0;
 const bool g_symmetric = getenv("TG_CONV3X3_SYMMETRIC") != nullptr;      // A/B: the symmetric (non role-specialised) 256-pixel kernel
 const int g_env_loaded = ([] { if (const char* e = getenv("TG_CONV3X3_BM")) g_force_bm = atoi(e); if (const char* e = getenv("TG_CONV3X3_DBG")) g_dbg = atoi(e); if (const char* e = getenv("TG_CONV3X3_STAGGER")) g_stagger = atoi(e); return 0; })();
-const bool g_disabled = getenv("TG_NO_CONV3X3_BF16") != nullptr;     // A/B switch, read once at library load
+const bool g_disabled = getenv("TG_NO_CONV3X3_BF16") != nullptr;     // A/B switches, read once at library load
+const bool g_disabled_f32 = getenv("TG_NO_CONV3X3_F32") != nullptr;
+
+int g_policy = 0;                      // tg_conv3x3_policy: 0 = where it pays (below), 1 = wherever it applies, 2 = never
+long g_launches = 0;
+
+int compute_units() {
+  static const int n = ([] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; })();
+  return n;
+}
 
 int pick_bm(const tg_igemm_desc* d) {
   const bool ok256 = d->h_in % (256 / d->w_in) == 0, ok128 = d->h_in % (128 / d->w_in) == 0;
@@ -647,14 +690,15 @@ int pick_bm(const tg_igemm_desc* d) {
 
 namespace tg {
 
-bool conv3x3_bf16_applicable(const tg_igemm_desc* d, int n_desc, const int32_t* seg_rows, int nseg) {
-  if (g_disabled) return false;
+bool conv3x3_bf16_applicable(const tg_igemm_desc* d, int n_desc, const int32_t* seg_rows, int nseg, bool bf16) {
+  if ((bf16 ? g_disabled : g_disabled_f32) || g_policy == 2) return false;
+  if (!bf16 && d->h_in % (256 / (d->w_in > 0 ? d->w_in : 1))) return false;          // the fp32 form exists for the 256-pixel tile only
   if (n_desc != 1 || d->n_taps != 9 || d->n_group != 0) return false;
   if (d->s_y != 1 || d->s_x != 1 || d->os_y != 1 || d->os_x != 1 || d->oo_y != 0 || d->oo_x != 0) return false;
   if (d->h_v != d->h_in || d->w_v != d->w_in || d->h_out != d->h_in || d->w_out != d->w_in) return false;
   if (d->w_in != 16 && d->w_in != 32 && d->w_in != 64) return false;
   if (pick_bm(d) == 0) return false;
-  if (d->ld_in % KC || d->c_out % BN) return false;
+  if (d->ld_in % (bf16 ? KC : 32) || d->c_out % BN) return false;
   bool seen[9] = {false, false, false, false, false, false, false, false, false};
   for (int t = 0; t < 9; ++t) {                               // the nine taps of a 3x3 window, each exactly once, in any order
     if (d->dy[t] < -1 || d->dy[t] > 1 || d->dx[t] < -1 || d->dx[t] > 1) return false;
@@ -665,12 +709,23 @@ bool conv3x3_bf16_applicable(const tg_igemm_desc* d, int n_desc, const int32_t* 
   const int per_img = d->h_in * d->w_in;
   for (int i = 0; i < nseg; ++i)
     if (seg_rows[i] % per_img) return false;                  // applications are whole images: a tile never straddles a segment
+  if (g_policy == 0) {
+    // One workgroup per CU (141-150 KB of LDS), so the launch runs in ceil(tiles / CUs) rounds and the last one may be nearly
+    // empty: 130 images of 32x32 are 520 tiles = 3 rounds on 256 CUs for 2.03 rounds of work.  The generic implicit GEMM (8 000
+    // small workgroups) has no such step, so the halo form is taken only where its per-tile advantage (measured, full rounds:
+    // 1.07x with fp32 operands, 1.9x with bf16 ones) survives the quantisation.
+    const int bm = bf16 ? pick_bm(d) : 256;
+    const long slots = (long)compute_units() * (bm == 128 ? 2 : 1);
+    const long tiles = (long)d->n_img * per_img / bm * (d->c_out / BN);
+    const long rounds = (tiles + slots - 1) / slots;
+    if ((double)tiles / (double)(rounds * slots) * (bf16 ? 1.8 : 1.07) < 1.0) return false;
+  }
   return true;
 }
 
 int conv3x3_bf16_launch(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, double* colsum,
                         const int32_t* seg_rows, int nseg, const float* ymul, int ymul_act, float ymul_alpha, uint32_t in_bytes, uint32_t w_bytes,
-                        uint32_t out_bytes, hipStream_t s) {
+                        uint32_t out_bytes, hipStream_t s, bool bf16) {
   ConvParams p;
   p.in = in; p.w = w; p.bias = bias; p.out = out; p.colsum = colsum; p.ymul = ymul; p.ymul_act = ymul_act; p.ymul_alpha = ymul_alpha;
   p.nseg = nseg;
@@ -679,13 +734,15 @@ int conv3x3_bf16_launch(const tg_igemm_desc* d, const float* in, const float* w,
   p.act = d->act; p.alpha = d->alpha;
   p.w_sn = d->w_sn; p.w_st = d->w_st;
   for (int t = 0; t < 9; ++t) p.tap[t] = ((int)d->tapw[t] << 16) | (((int)d->dy[t] & 0xff) << 8) | ((int)d->dx[t] & 0xff);
-  const int bm = pick_bm(d);
+  const int bm = bf16 ? pick_bm(d) : 256;
+  p.f32 = bf16 ? 0 : 1;
   p.dbg = g_dbg;
   p.stagger = g_stagger;
   p.n_tiles_m = d->n_img * d->h_in * d->w_in / bm;
   p.n_tiles_n = d->c_out / BN;
   p.in_bytes = in_bytes; p.w_bytes = w_bytes; p.out_bytes = out_bytes;
-  if (bm == 256 && !g_symmetric) {
+  ++g_launches;
+  if (bm == 256 && (!g_symmetric || !bf16)) {
     if (d->w_in == 16) launch_ws<16>(p, s);
     else if (d->w_in == 32) launch_ws<32>(p, s);
     else launch_ws<64>(p, s);
@@ -703,6 +760,14 @@ int conv3x3_bf16_launch(const tg_igemm_desc* d, const float* in, const float* w,
 }
 
 }  // namespace tg
+
+extern "C" int tg_conv3x3_policy(int policy) {
+  const int was = g_policy;
+  if (policy >= 0 && policy <= 2) g_policy = policy;
+  return was;
+}
+
+extern "C" int64_t tg_conv3x3_launches(void) { return g_launches; }
 
 #ifdef TG_STAMP
 extern "C" int tg_debug_read_conv_stamps(unsigned long long* out) {

@@ -759,8 +759,8 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
            bf16 ? " bf16" : "");
   hipStream_t s = tg::as_stream(stream);
   tg::ProfScope prof(tg::PC_IGEMM, flops, bytes, s, desc);
-  if (bf16 && tg::conv3x3_bf16_applicable(descs, n_desc, seg_rows, colsum ? nseg : 0))      // the classifier's 3x3 layers: halo-tiled kernel
-    return tg::conv3x3_bf16_launch(d, in, w, bias, out, colsum, seg_rows, nseg, ymul, ymul_act, ymul_alpha, p.in_bytes, p.w_bytes, p.out_bytes, s);
+  if (tg::conv3x3_bf16_applicable(descs, n_desc, seg_rows, colsum ? nseg : 0, bf16))      // the classifier's 3x3 layers: halo-tiled kernel (both operand types)
+    return tg::conv3x3_bf16_launch(d, in, w, bias, out, colsum, seg_rows, nseg, ymul, ymul_act, ymul_alpha, p.in_bytes, p.w_bytes, p.out_bytes, s, bf16);
   // tile choice by the quantisation cost model of geom.cpp (tg::igemm_pick_tile; also behind tg_igemm_tile / tg_igemm_colsum_supported)
   int bm = 0, bn = 0;
   TG_REQUIRE(tg::igemm_pick_tile(descs, n_desc, colsum != nullptr, seg_rows, nseg, bf16, &bm, &bn), "igemm: no tile fits c_out=%d with the given segments",

@@ -8,9 +8,9 @@ namespace tg {
 
 // 9 taps of a 3x3 window, stride 1, output grid = input grid (SAME), width 16 / 32 / 64 with 256 / width dividing the height, 64 | ld_in,
 // 128 | c_out, segments of whole images
-bool conv3x3_bf16_applicable(const tg_igemm_desc* d, int n_desc, const int32_t* seg_rows, int nseg);
+bool conv3x3_bf16_applicable(const tg_igemm_desc* d, int n_desc, const int32_t* seg_rows, int nseg, bool bf16);   // bf16 = false: the exact-fp32 form (32 | ld_in)
 int conv3x3_bf16_launch(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, double* colsum,
                         const int32_t* seg_rows, int nseg, const float* ymul, int ymul_act, float ymul_alpha, uint32_t in_bytes, uint32_t w_bytes,
-                        uint32_t out_bytes, hipStream_t s);
+                        uint32_t out_bytes, hipStream_t s, bool bf16);
 
 }  // namespace tg

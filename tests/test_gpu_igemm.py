@@ -16,6 +16,21 @@ def _tg():
     return lib, geom
 
 
+@pytest.fixture(autouse=True)
+def _halo_kernel_wherever_it_applies():
+    """kernel tests run the halo-tiled 3x3 kernel on every shape it accepts (policy 1); the default policy routes launches too small
+    to fill whole rounds of one workgroup per CU to the generic kernel (include/tg_kernels.h: tg_conv3x3_policy)."""
+    lib, _ = _tg()
+    was = lib.call('tg_conv3x3_policy', 1)
+    yield
+    lib.call('tg_conv3x3_policy', was)
+
+
+def _takes_halo_kernel(prec, h, w, ci_p, co_p, k, s, pad):
+    return (k == 3 and s == 1 and pad == 'SAME' and w in (16, 32, 64) and h % (256 // w) == 0 and ci_p % (64 if prec == 'bf16' else 32) == 0
+            and co_p % 128 == 0)
+
+
 def dev(x):
     return torch.from_numpy(np.ascontiguousarray(x)).cuda()
 
@@ -79,7 +94,9 @@ def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad, prec):
     xd, wd, bd = dev(padc(x, ci_p)), dev(w_oti), dev(padc(bias, co_p))
     yd = torch.full((n, ho, wo, co_p), 7.0, device='cuda')
     d = geom.conv_fwd(n, h, w, ci_p, co_p, k, s, pad, act='lrelu')
+    halo0 = lib.call('tg_conv3x3_launches')
     lib.call("tg_igemm_" + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
+    assert lib.call('tg_conv3x3_launches') - halo0 == int(_takes_halo_kernel(prec, h, w, ci_p, co_p, k, s, pad))
     y = yd.cpu().numpy()
     close(y[..., :cout], y_ref, scale)
     assert (y[..., cout:] == 0).all()
@@ -93,8 +110,10 @@ def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad, prec):
     dxd = torch.full((n, h, w, ci_p), 7.0, device='cuda')
     descs = geom.conv_dgrad(n, h, w, ci_p, co_p, k, s, pad)
     assert len(descs) == s * s
+    halo0 = lib.call('tg_conv3x3_launches')
     for dd in descs:
         lib.call("tg_igemm_" + prec, dd, lib.ptr(dyd), lib.ptr(whd), None, lib.ptr(dxd), lib.cur_stream())
+    assert lib.call('tg_conv3x3_launches') - halo0 == int(_takes_halo_kernel(prec, h, w, co_p, ci_p, k, s, pad))
     dx = dxd.cpu().numpy()
     close(dx[..., :cin], dx_ref, np.abs(dy).max() * np.abs(wt).max() * k * k * cout)
     assert (dx[..., cin:] == 0).all()

@@ -224,7 +224,10 @@ def test_fused_mean_only_batch_norm_forward_backward(prec, segs, h):
     yd = torch.full((n, h, w, cout), 7.0, device='cuda')
     sums = torch.zeros(16 * len(segs) * cout, device='cuda')         # room for the 8 accumulator replicas of tg_mobn_bwd_f32
     d = geom.conv_fwd(n, h, w, cin, cout, 3, 1, 'SAME')
+    was, halo0 = lib.call('tg_conv3x3_policy', 1), lib.call('tg_conv3x3_launches')        # the halo kernel wherever the layer applies
     lib.call('tg_igemm_colsum_' + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(yd), sa, len(segs), lib.ptr(sums), 0, st())
+    lib.call('tg_conv3x3_policy', was)
+    assert lib.call('tg_conv3x3_launches') - halo0 == int(h in (16, 32))
     pre_hip = yd.cpu().numpy().copy()
     scale = np.abs(x).max() * np.abs(wt).max() * 9 * cin
     assert np.abs(pre_hip - pre).max() <= 3e-5 * scale

@@ -5,8 +5,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=${1:-r01}
 O=gpurun_out/profiles_$R
 mkdir -p $O
-python3 bench.py --steps 30 --warmup 5 > $O/bench.json 2> $O/bench.err
+python3 bench.py > $O/bench.json 2> $O/bench.err
 TG_PROF_DUMP=$O/launches.csv python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --prof-iters 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/rp_bench.json 2> $O/rp.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp -- python3 bench.py --no-cpu-baseline > $O/rp_bench.json 2> $O/rp.err
 cp $O/rp/*/*kernel_stats.csv $O/kernel_stats.csv
 tail -c 400 $O/bench.json
