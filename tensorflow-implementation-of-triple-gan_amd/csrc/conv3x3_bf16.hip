@@ -55,6 +55,10 @@ __device__ unsigned long long tg_conv_stamps[8 * 64];
 #define LSTAMP(var) do {} while (0)
 #endif
 
+#ifndef TG_ABL
+#define TG_ABL 0                               // timing ablations of conv3x3_pipe_kernel (tools only, results then wrong): 1 no stores, 8 half the halo loads, 16 half the filter loads, 32 no MFMAs
+#endif
+
 namespace {
 
 constexpr int BN = 128, KC = 64;               // output channels per tile, channels per chunk
@@ -81,6 +85,11 @@ struct ConvParams {
   int dbg;                                     // TG_CONV3X3_DBG (diagnostic timing only, results then wrong): 1 no stores, 2 no filter loads in the loop, 4 no MFMAs, 8 no halo reload
 };
 
+int compute_units() {
+  static const int n = ([] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; })();
+  return n;
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
@@ -99,6 +108,12 @@ __device__ __forceinline__ u32x2 pack4(u32x4 v) {             // 4 fp32 -> 4 bf1
   r.x = pack2(v.x, v.y);
   r.y = pack2(v.z, v.w);
   return r;
+}
+
+// v + (v of the lane the DPP control names); lanes the row mask excludes add 0
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
 }
 
 // LDS byte offset of 16-B chunk `chunk` (8 bf16) of row `row`: 128-B rows, chunk index XOR-swizzled with bits 1..3 of the row.
@@ -512,7 +527,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvParams p) {
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    CSTAMP(1);
     __syncthreads();                                            // (P)
+    CSTAMP(2);
     int bbuf = 0;
     for (int c = 0; c < nchunks; ++c) {
       const bool more_c = c + 1 < nchunks;
@@ -656,6 +673,440 @@ void launch_ws(ConvParams& p, hipStream_t s) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Persistent, tile-pipelined form of the role-specialised kernel (the default).  Stamped on the form above (conv1_2, bf16 operands): of
+// a workgroup's 59 k cycles 13 k are the prologue (first halo + filter group: HBM / L2 latency with the matrix pipe idle), 29 k the K
+// loop and 17 k the epilogue (128 KB staged through LDS and stored by all eight waves) — one workgroup per CU, so nothing else runs
+// on the CU meanwhile, and all 256 workgroups of a round are in the same phase at once (HBM idle during the K loops, matrix pipes idle
+// during loads and stores).  Here a workgroup stays resident and walks its share of the tiles:
+//   * the loaders treat (tile, chunk, tap group) as ONE stream — the first halo and filter group of the next tile are fetched during the
+//     last steps of the current one, so only a workgroup's first tile pays a prologue;
+//   * the consumers store their accumulators straight from registers (lane = channel: each half-wave writes one 128-B line of a pixel;
+//     bias / activation, the activation-gradient multiplier and the column sums are per lane) — no LDS staging, no barrier, and the
+//     stores drain while the next tile's MFMAs run;
+//   * column sums: per wave in registers, one LDS slot per consumer wave, summed and added to the global accumulator (one double
+//     atomic per channel and tile, as before) by the loader waves after the next barrier.
+// Tile order: XCD x (= blockIdx & 7) owns a contiguous eighth of the tiles (neighbouring tiles share halo rows and all share the filter
+// in that XCD's L2); its 32 workgroups stride through it.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int W, bool COLSUM, bool BF16>
+__global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
+  constexpr int BM = 256, TPS = 3, NG = 3;
+  constexpr int KCH = BF16 ? 64 : 32;
+  constexpr int UPR = BF16 ? 16 : 8;
+  constexpr int RPP = 256 / UPR;
+  constexpr int R = BM / W, HW_ = W + 2, HP = (R + 2) * HW_;
+  constexpr int A_BYTES = (HP * 128 + 255) / 256 * 256, B_TAP = BN * 128, B_BYTES = TPS * B_TAP;
+  constexpr int A_IT = (HP + RPP - 1) / RPP, B_IT = BN / RPP;
+  constexpr int MAIN_BYTES = A_BYTES + 2 * B_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + 2 * 4 * BN * 4];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + A_BYTES;
+  float* red = reinterpret_cast<float*>(smem + MAIN_BYTES);       // [tile parity][consumer wave][BN] column sums
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntiles = p.n_tiles_m * p.n_tiles_n;
+  int t, t_end, t_stride;
+  if ((gridDim.x & 7) == 0) {
+    const int x = blockIdx.x & 7, q = ntiles >> 3, r = ntiles & 7;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    t = start + (blockIdx.x >> 3);
+    t_end = start + q + (x < r ? 1 : 0);
+    t_stride = gridDim.x >> 3;
+  } else {
+    t = blockIdx.x;
+    t_end = ntiles;
+    t_stride = gridDim.x;
+  }
+  if (t >= t_end) return;
+  const int nchunks = p.ld_in / KCH;
+  const int tiles_per_img = p.h / R;
+  const int half = lane >> 5, col = lane & 31;
+
+  if (wave >= 4) {
+    // ================================================= loaders =====================================================================
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    const int lt = tid - 256;
+    const int qu = lt % UPR, row_t = lt / UPR;
+    const int st_lds = BF16 ? lds_off(row_t, qu >> 1) + (qu & 1) * 8 : lds_off(row_t, qu);
+    uint32_t a_voff[A_IT];
+    uint32_t b_voff;
+    const uint32_t b_pass = (uint32_t)(RPP * p.w_sn * 4);
+    auto set_tile_a = [&](int tt) {
+      const int mt = tt / p.n_tiles_n;
+      const int img = mt / tiles_per_img, row0 = (mt - img * tiles_per_img) * R;
+      int rt = row_t;
+      asm volatile("" : "+v"(rt));                              // keeps the per-pass halo coordinates from being hoisted out of the tile loop (22 x 2 registers)
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int hp = rt + RPP * i;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int iy = row0 + hy - 1, ix = hx - 1;
+        const bool ok = hp < HP && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)W;
+        a_voff[i] = ok ? (uint32_t)(((img * p.h + iy) * W + ix) * p.ld_in + 4 * qu) * 4u : OOB;
+      }
+    };
+    auto set_tile_b = [&](int tt) { b_voff = (uint32_t)(((int64_t)((tt % p.n_tiles_n) * BN + row_t) * p.w_sn + 4 * qu) * 4); };
+    // The next halo waits in registers from step g = 1 (loads issued, after that step's filter group has been written, so that the two
+    // register images are never live together) to the end of step g = 2; with bf16 operands it is packed at the top of step 2
+    // (88 -> 44 registers) before that step's filter loads take their 96.
+    u32x4 ra[A_IT], rb[TPS * B_IT];
+    u32x2 rap[BF16 ? A_IT : 1];
+    auto gload_a = [&](int c0) {
+      const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(c0 * 4);
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i)
+        if (!(TG_ABL & 8) || i < A_IT / 2) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_voff[i], so, 0);
+    };
+    auto pack_a = [&]() {
+      if constexpr (BF16) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) rap[i] = pack4(ra[i]);
+      }
+    };
+    auto put = [&](unsigned char* dst, u32x4 v) {
+      if constexpr (BF16) *reinterpret_cast<u32x2*>(dst) = pack4(v);
+      else *reinterpret_cast<u32x4*>(dst) = v;
+    };
+    auto sstore_a = [&]() {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i)
+        if (i + 1 < A_IT || row_t + RPP * i < HP) {
+          if constexpr (BF16) *reinterpret_cast<u32x2*>(As + st_lds + i * RPP * 128) = rap[i];
+          else *reinterpret_cast<u32x4*>(As + st_lds + i * RPP * 128) = ra[i];
+        }
+    };
+    auto gload_b = [&](int g, int c0) {
+#pragma unroll
+      for (int k = 0; k < TPS; ++k) {
+        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(((p.tap[TPS * g + k] >> 16) * (int)p.w_st + c0) * 4);
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j)
+          if (!(TG_ABL & 16) || j < B_IT / 2) rb[k * B_IT + j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_voff, so + j * b_pass, 0);
+      }
+    };
+    auto sstore_b = [&](int buf) {
+      unsigned char* b = Bs + buf * B_BYTES + st_lds;
+#pragma unroll
+      for (int k = 0; k < TPS; ++k)
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) put(b + k * B_TAP + j * RPP * 128, rb[k * B_IT + j]);
+    };
+    auto flush = [&](int tt, int parity) {                      // column sums of tile tt: the four consumer slots -> one double atomic per channel
+      if (lt < BN) {
+        const int nt = tt % p.n_tiles_n, m0 = (tt / p.n_tiles_n) * BM;
+        int seg = 0, acc_rows = p.seg_rows[0];
+        while (seg < p.nseg - 1 && m0 >= acc_rows) acc_rows += p.seg_rows[++seg];
+        const float* rp = red + parity * 4 * BN + lt;
+        const float s1 = (rp[0] + rp[BN]) + (rp[2 * BN] + rp[3 * BN]);
+        if (nt * BN + lt < p.n_store) atomicAdd(p.colsum + (int64_t)seg * p.c_out + nt * BN + lt, (double)s1);
+      }
+    };
+    set_tile_a(t);
+    set_tile_b(t);
+    gload_a(0);
+    pack_a();
+    sstore_a();
+    gload_b(0, 0);
+    sstore_b(0);
+    __syncthreads();                                            // (P) operands of the first step are in LDS
+    int bbuf = 0, k_tile = 0;
+    while (true) {
+      const int tn = t + t_stride;
+      const bool has_next = tn < t_end;
+      for (int c = 0; c < nchunks; ++c) {
+        const bool last_c = c + 1 == nchunks;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const bool last_g = g == NG - 1;
+          const bool more = !(last_g && last_c) || has_next;
+          if (more) {
+            if (last_g) pack_a();
+            if (!last_g) {
+              gload_b(g + 1, c * KCH);
+            } else if (!last_c) {
+              gload_b(0, (c + 1) * KCH);
+            } else {
+              set_tile_b(tn);
+              gload_b(0, 0);
+            }
+            sstore_b(bbuf ^ 1);                                 // the other filter buffer: last read one step ago
+            if (g == 1) {
+              if (!last_c) {
+                gload_a((c + 1) * KCH);
+              } else if (has_next) {
+                set_tile_a(tn);
+                gload_a(0);
+              }
+            }
+          }
+          __syncthreads();                                      // (S) the consumers are done with this step
+          if (COLSUM && c == 0 && g == 0 && k_tile > 0) flush(t - t_stride, (k_tile - 1) & 1);
+          if (last_g && more) {
+            sstore_a();                                         // the ONE halo buffer: free now
+            __syncthreads();                                    // (H)
+          }
+          bbuf ^= 1;
+        }
+      }
+      if (!has_next) break;
+      t = tn;
+      ++k_tile;
+    }
+    if (COLSUM) {
+      __syncthreads();                                          // (F) the consumers' last column sums are in LDS
+      flush(t, k_tile & 1);
+    }
+  } else {
+    // ================================================= consumers ===================================================================
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ymul ? p.ymul : p.out), 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias ? p.bias : p.w), 0, p.bias ? (uint32_t)p.n_store * 4u : 0u, 0x00020000);
+    const bool ym = COLSUM && p.ymul != nullptr;
+    const int wm0 = wave * 64;
+    int a_hp[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int r = wm0 + mi * 32 + col;
+      const int ty = r / W, tx = r - ty * W;
+      a_hp[mi] = (ty + 1) * HW_ + tx + 1;
+    }
+    int b_off[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) b_off[ni] = (ni * 32 + col) * 128;
+    const int b_swz = (col >> 1) & 7;
+    f32x16 acc[2][4];
+#ifdef TG_STAMP
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, sum_k = 0, sum_e = 0, sum_b = 0, tb0 = 0, tb1 = 0;
+    LSTAMP(ts0);
+#endif
+    __syncthreads();                                            // (P)
+#ifdef TG_STAMP
+    LSTAMP(ts1);
+#endif
+    int bbuf = 0, k_tile = 0;
+    while (true) {
+      const int tn = t + t_stride;
+      const bool has_next = tn < t_end;
+#ifdef TG_STAMP
+      LSTAMP(ts2);
+#endif
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+      for (int c = 0; c < nchunks; ++c) {
+        const bool last_c = c + 1 == nchunks;
+#pragma unroll 1
+        for (int g = 0; g < NG; ++g) {
+          const bool last_g = g == NG - 1;
+          const bool more = !(last_g && last_c) || has_next;
+          const unsigned char* B = Bs + bbuf * B_BYTES;
+#pragma unroll
+          for (int k = 0; k < TPS; ++k) {
+            const int tp = p.tap[TPS * g + k];
+            const int shift = (int)(int8_t)(tp >> 8) * HW_ + (int)(int8_t)tp;
+            int a_row[2], a_swz[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+              const int hp = a_hp[mi] + shift;
+              a_row[mi] = hp * 128;
+              a_swz[mi] = (hp >> 1) & 7;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              if constexpr (BF16) {
+                bf16x8 a[2], b[4];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(As + a_row[mi] + (((2 * s + half) ^ a_swz[mi]) << 4));
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(B + k * B_TAP + b_off[ni] + (((2 * s + half) ^ b_swz) << 4));
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                  for (int ni = 0; ni < 4; ++ni)
+                    if (!(TG_ABL & 32)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);   // D[channel][pixel]: lane = pixel
+              } else {
+                f32x4 a[2], b[4];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(As + a_row[mi] + (((2 * s + half) ^ a_swz[mi]) << 4));
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(B + k * B_TAP + b_off[ni] + (((2 * s + half) ^ b_swz) << 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][e], a[mi][e], acc[mi][ni], 0, 0, 0);
+              }
+            }
+          }
+#ifdef TG_STAMP
+          LSTAMP(tb0);
+#endif
+          __syncthreads();                                      // (S)
+          if (last_g && more) __syncthreads();                  // (H)
+#ifdef TG_STAMP
+          LSTAMP(tb1);
+          sum_b += tb1 - tb0;
+#endif
+          bbuf ^= 1;
+        }
+      }
+#ifdef TG_STAMP
+      LSTAMP(ts3);
+      sum_k += ts3 - ts2;
+#endif
+      // ---- epilogue of tile t: registers -> global.  Tiles are whole rows of whole images, so the tile's pixels are consecutive
+      // rows of the [pixels][ld_out] output.  D[channel][pixel]: lane = pixel mi*32 + col, registers 4q..4q+3 of fragment ni = the FOUR
+      // CONSECUTIVE channels ni*32 + 8q + 4*half + (0..3) -> one 16-byte store per (mi, ni, q): 32 store instructions per wave and tile
+      // (with lane = channel they were 128 dword stores, and the store tail is bound by instruction issue, not by bytes).
+      {
+        const int n0 = (t % p.n_tiles_n) * BN;
+        uint32_t px0 = (uint32_t)((t / p.n_tiles_n) * BM + wm0 + col);
+        asm volatile("" : "+v"(px0));                             // per-tile value: keeps the address arithmetic below out of the registers during the K loop
+        const uint32_t row_bytes = (uint32_t)p.ld_out * 4u;
+        const bool wide = (p.n_store & 3) == 0;
+        auto store4 = [&](uint32_t rowoff, int n, float v0, float v1, float v2, float v3) {
+          if (TG_ABL & 1) return;
+          if (wide) {
+            const u32x4 pk = {__builtin_bit_cast(uint32_t, v0), __builtin_bit_cast(uint32_t, v1), __builtin_bit_cast(uint32_t, v2), __builtin_bit_cast(uint32_t, v3)};
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rs_o, n < p.n_store ? rowoff + (uint32_t)n * 4u : OOB, 0, 0);
+          } else {
+            const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv[e]), rs_o, n + e < p.n_store ? rowoff + (uint32_t)(n + e) * 4u : OOB, 0, 0);
+          }
+        };
+        if (!COLSUM) {
+          // bias + activation; only y = x > 0 ? x : slope * x forms reach this kernel (none / relu / leaky relu: conv3x3_bf16_launch)
+          const float slope = p.act == TG_ACT_LRELU ? p.alpha : (p.act == TG_ACT_RELU ? 0.f : 1.f);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            float bv[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const u32x4 bq = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)(n0 + ni * 32 + 8 * q + 4 * half) * 4u, 0, 0);   // beyond n_store: 0
+              const uint32_t b0 = bq.x, b1 = bq.y, b2 = bq.z, b3 = bq.w;
+              bv[4 * q] = __builtin_bit_cast(float, b0);
+              bv[4 * q + 1] = __builtin_bit_cast(float, b1);
+              bv[4 * q + 2] = __builtin_bit_cast(float, b2);
+              bv[4 * q + 3] = __builtin_bit_cast(float, b3);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+              const uint32_t rowoff = (px0 + (uint32_t)(mi * 32)) * row_bytes;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float x = acc[mi][ni][4 * q + e] + bv[4 * q + e];
+                  v[e] = x > 0.f ? x : slope * x;
+                }
+                store4(rowoff, n0 + ni * 32 + 8 * q + 4 * half, v[0], v[1], v[2], v[3]);
+              }
+            }
+          }
+        } else {
+          if (ym) {
+            // the multiplier act'(y) is read at the output's own addresses, one fragment (4 x 16 bytes per lane) ahead of its use
+            const float slope = p.ymul_act == TG_ACT_LRELU ? p.ymul_alpha : (p.ymul_act == TG_ACT_RELU ? 0.f : 1.f);
+            u32x4 yv[2][4];
+            auto yload = [&](int f, int buf) {
+              const int ni = f >> 1, mi = f & 1;
+              const uint32_t rowoff = (px0 + (uint32_t)(mi * 32)) * row_bytes;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int n = n0 + ni * 32 + 8 * q + 4 * half;
+                yv[buf][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, n < p.n_store ? rowoff + (uint32_t)n * 4u : OOB, 0, 0);
+              }
+            };
+            yload(0, 0);
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+              const int ni = f >> 1, mi = f & 1;
+              if (f + 1 < 8) yload(f + 1, (f + 1) & 1);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const u32x4 yq = yv[f & 1][q];
+                const uint32_t y0 = yq.x, y1 = yq.y, y2 = yq.z, y3 = yq.w;     // scalars first (ext-vector element bit-casts: see the symmetric kernel)
+                const float yy[4] = {__builtin_bit_cast(float, y0), __builtin_bit_cast(float, y1), __builtin_bit_cast(float, y2), __builtin_bit_cast(float, y3)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  acc[mi][ni][4 * q + e] *= yy[e] > 0.f ? 1.f : slope;
+              }
+            }
+          }
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+              const uint32_t rowoff = (px0 + (uint32_t)(mi * 32)) * row_bytes;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                store4(rowoff, n0 + ni * 32 + 8 * q + 4 * half, acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+            }
+            // column sums of this wave's 64 pixels: two pixels per lane, then across the 32 lanes of each half (DPP butterfly inside the
+            // 16-lane rows, row_bcast15 into rows 1 and 3); lanes 31 / 63 write their half's 4 x 4 channels of fragment ni
+            float cs[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float v = acc[0][ni][r] + acc[1][ni][r];
+              v = dpp_add<0xB1>(v);                              // quad_perm [1,0,3,2]
+              v = dpp_add<0x4E>(v);                              // quad_perm [2,3,0,1]
+              v = dpp_add<0x141>(v);                             // row_half_mirror
+              v = dpp_add<0x140>(v);                             // row_mirror
+              cs[r] = dpp_add<0x142, 0xA>(v);                    // row_bcast15 into rows 1, 3
+            }
+            if (col == 31) {
+              float* rp = red + ((k_tile & 1) * 4 + wave) * BN + ni * 32 + 4 * half;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(rp + 8 * q) = make_float4(cs[4 * q], cs[4 * q + 1], cs[4 * q + 2], cs[4 * q + 3]);
+            }
+          }
+        }
+      }
+#ifdef TG_STAMP
+      LSTAMP(ts2);
+      sum_e += ts2 - ts3;
+#endif
+      if (!has_next) break;
+      t = tn;
+      ++k_tile;
+    }
+#ifdef TG_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 64) {                  // consumer wave 0: first barrier wait | K loops | of which at barriers | epilogues | total | tiles
+      tg_conv_stamps[0 * 64 + blockIdx.x] = ts1 - ts0;
+      tg_conv_stamps[1 * 64 + blockIdx.x] = sum_k;
+      tg_conv_stamps[2 * 64 + blockIdx.x] = sum_b;
+      tg_conv_stamps[3 * 64 + blockIdx.x] = sum_e;
+      tg_conv_stamps[4 * 64 + blockIdx.x] = ts2 - ts0;
+      tg_conv_stamps[5 * 64 + blockIdx.x] = (unsigned long long)(k_tile + 1);
+    }
+#endif
+    if (COLSUM) __syncthreads();                                // (F)
+  }
+}
+
+template <int W>
+void launch_pipe(ConvParams& p, hipStream_t s) {
+  const int tiles = p.n_tiles_m * p.n_tiles_n, cus = compute_units();
+  const dim3 grid(tiles < cus ? tiles : cus);                  // one resident workgroup per CU (LDS), each walking its share of the tiles
+  if (p.f32) {
+    if (p.colsum) hipLaunchKernelGGL((conv3x3_pipe_kernel<W, true, false>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_pipe_kernel<W, false, false>), grid, dim3(512), 0, s, p);
+  } else {
+    if (p.colsum) hipLaunchKernelGGL((conv3x3_pipe_kernel<W, true, true>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_pipe_kernel<W, false, true>), grid, dim3(512), 0, s, p);
+  }
+}
+
 template <int W, int BM, int TPS>
 void launch(ConvParams& p, hipStream_t s) {
   const dim3 grid(p.n_tiles_m * p.n_tiles_n);
@@ -668,16 +1119,13 @@ void launch(ConvParams& p, hipStream_t s) {
 int g_force_bm = 0, g_dbg = 0, g_stagger = 0;
 const bool g_symmetric = getenv("TG_CONV3X3_SYMMETRIC") != nullptr;      // A/B: the symmetric (non role-specialised) 256-pixel kernel
 const int g_env_loaded = ([] { if (const char* e = getenv("TG_CONV3X3_BM")) g_force_bm = atoi(e); if (const char* e = getenv("TG_CONV3X3_DBG")) g_dbg = atoi(e); if (const char* e = getenv("TG_CONV3X3_STAGGER")) g_stagger = atoi(e); return 0; })();
+const bool g_pipe_colsum = getenv("TG_CONV3X3_PIPE_COLSUM") != nullptr;
+const bool g_staged = getenv("TG_CONV3X3_STAGED") != nullptr;            // A/B: one tile per workgroup, LDS-staged epilogue (conv3x3_ws_kernel)
 const bool g_disabled = getenv("TG_NO_CONV3X3_BF16") != nullptr;     // A/B switches, read once at library load
 const bool g_disabled_f32 = getenv("TG_NO_CONV3X3_F32") != nullptr;
 
 int g_policy = 0;                      // tg_conv3x3_policy: 0 = where it pays (below), 1 = wherever it applies, 2 = never
 long g_launches = 0;
-
-int compute_units() {
-  static const int n = ([] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; })();
-  return n;
-}
 
 int pick_bm(const tg_igemm_desc* d) {
   const bool ok256 = d->h_in % (256 / d->w_in) == 0, ok128 = d->h_in % (128 / d->w_in) == 0;
@@ -742,7 +1190,14 @@ int conv3x3_bf16_launch(const tg_igemm_desc* d, const float* in, const float* w,
   p.n_tiles_n = d->c_out / BN;
   p.in_bytes = in_bytes; p.w_bytes = w_bytes; p.out_bytes = out_bytes;
   ++g_launches;
-  if (bm == 256 && (!g_symmetric || !bf16)) {
+  const auto simple = [](int a) { return a == TG_ACT_NONE || a == TG_ACT_LRELU || a == TG_ACT_RELU; };
+  // measured (N = 250, bf16): without column sums the pipelined form is 8-13 % faster on the 32x32 and 16x16/128-channel layers and 3 % slower
+  // on conv2_2; with them (32-lane register reductions in the epilogue) it is 5-15 % slower than the staged form -> TG_CONV3X3_PIPE_COLSUM opts in
+  if (bm == 256 && !g_staged && (!g_symmetric || !bf16) && simple(d->act) && (ymul == nullptr || simple(ymul_act)) && (colsum == nullptr || g_pipe_colsum)) {
+    if (d->w_in == 16) launch_pipe<16>(p, s);
+    else if (d->w_in == 32) launch_pipe<32>(p, s);
+    else launch_pipe<64>(p, s);
+  } else if (bm == 256 && (!g_symmetric || !bf16)) {
     if (d->w_in == 16) launch_ws<16>(p, s);
     else if (d->w_in == 32) launch_ws<32>(p, s);
     else launch_ws<64>(p, s);
