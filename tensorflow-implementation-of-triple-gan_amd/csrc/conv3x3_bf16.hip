@@ -80,6 +80,7 @@ struct ConvParams {
   int tap[9];                                  // (tapw << 16) | ((dy & 0xff) << 8) | (dx & 0xff)
   int n_tiles_m, n_tiles_n;
   uint32_t in_bytes, w_bytes, out_bytes;
+  const void* wpk;                             // bf16 filter packed as consecutive LDS images (filter_pack_kernel) — conv3x3_pipe_kernel<.., BF16 = true>
   int f32;                                     // 1: exact-fp32 operands (conv3x3_ws_kernel<..., BF16 = false>)
   int stagger;                                 // first-round delay (in units of ~1k cycles) of every second workgroup slot: see the kernel
   int dbg;                                     // TG_CONV3X3_DBG (diagnostic timing only, results then wrong): 1 no stores, 2 no filter loads in the loop, 4 no MFMAs, 8 no halo reload
@@ -673,6 +674,27 @@ void launch_ws(ConvParams& p, hipStream_t s) {
   }
 }
 
+// fp32 filter -> bf16, laid out as the consecutive LDS images the pipelined kernel's steps consume: image (nt, chunk, tap index k9 in the
+// descriptor's tap order) = 128 filter rows x 64 channels = 16 KB with the 16-byte chunks XOR-swizzled exactly as lds_off() places them,
+// so that a step's three images (48 KB) go global -> LDS by LDS-DMA as they stand (1 KB per wave-instruction, no registers, no
+// conversion, no ds_write) and every workgroup fetches half the bytes from L2.  One thread per 16-byte chunk; ~150 k - 600 k elements.
+__global__ void __launch_bounds__(256) filter_pack_kernel(ConvParams p, int nchunks, int total) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= total) return;
+  const int q = u & 7, r = (u >> 3) & 127, img = u >> 10;
+  const int k9 = img % 9, c = (img / 9) % nchunks, nt = img / (9 * nchunks);
+  const float* src = p.w + (int64_t)(nt * BN + r) * p.w_sn + (int64_t)(p.tap[k9] >> 16) * p.w_st + c * KC + 8 * q;
+  const u32x4 lo = *reinterpret_cast<const u32x4*>(src), hi = *reinterpret_cast<const u32x4*>(src + 4);
+  const u32x2 a = pack4(lo), b = pack4(hi);
+  u32x4 o;
+  o.x = a.x; o.y = a.y; o.z = b.x; o.w = b.y;
+  *reinterpret_cast<u32x4*>(static_cast<unsigned char*>(const_cast<void*>(p.wpk)) + (size_t)img * (BN * 128) + lds_off(r, q)) = o;
+}
+
+// s_waitcnt vmcnt(N) lgkmcnt(0) + s_barrier: the N youngest vector-memory operations of this wave stay in flight across the barrier
+template <int N>
+__device__ __forceinline__ void barrier_keep() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Persistent, tile-pipelined form of the role-specialised kernel (the default).  Stamped on the form above (conv1_2, bf16 operands): of
 // a workgroup's 59 k cycles 13 k are the prologue (first halo + filter group: HBM / L2 latency with the matrix pipe idle), 29 k the K
@@ -719,6 +741,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
     t_stride = gridDim.x;
   }
   if (t >= t_end) return;
+  if (p.stagger > 0) {                                          // TG_CONV3X3_STAGGER (experiment): workgroup slot j of an XCD starts (j & 3) * stagger * ~1k cycles late
+    const int d = ((blockIdx.x >> 3) & 3) * p.stagger;
+    for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   const int nchunks = p.ld_in / KCH;
   const int tiles_per_img = p.h / R;
   const int half = lane >> 5, col = lane & 31;
@@ -747,11 +773,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
         a_voff[i] = ok ? (uint32_t)(((img * p.h + iy) * W + ix) * p.ld_in + 4 * qu) * 4u : OOB;
       }
     };
-    auto set_tile_b = [&](int tt) { b_voff = (uint32_t)(((int64_t)((tt % p.n_tiles_n) * BN + row_t) * p.w_sn + 4 * qu) * 4); };
+    int nt_b = 0, bbuf_w = 0;                                   // filter column tile the fetches read; filter buffer the next fetch fills
+    auto set_tile_b = [&](int tt) {
+      nt_b = tt % p.n_tiles_n;
+      b_voff = (uint32_t)(((int64_t)(nt_b * BN + row_t) * p.w_sn + 4 * qu) * 4);
+    };
     // The next halo waits in registers from step g = 1 (loads issued, after that step's filter group has been written, so that the two
     // register images are never live together) to the end of step g = 2; with bf16 operands it is packed at the top of step 2
     // (88 -> 44 registers) before that step's filter loads take their 96.
-    u32x4 ra[A_IT], rb[TPS * B_IT];
+    u32x4 ra[A_IT], rb[BF16 ? 1 : TPS * B_IT];
     u32x2 rap[BF16 ? A_IT : 1];
     auto gload_a = [&](int c0) {
       const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(c0 * 4);
@@ -777,21 +807,34 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
           else *reinterpret_cast<u32x4*>(As + st_lds + i * RPP * 128) = ra[i];
         }
     };
+    // filter group (three taps) of the next step.  fp32 operands: global -> registers (gload_b) -> LDS (sstore_b).  bf16 operands: the
+    // packed images go straight to LDS (gload_b: 12 LDS-DMA instructions of 1 KB per loader wave), nothing left for sstore_b.
     auto gload_b = [&](int g, int c0) {
+      if constexpr (BF16) {
+        const unsigned char* src = static_cast<const unsigned char*>(p.wpk) + ((size_t)((nt_b * nchunks + c0 / KCH) * NG + g)) * B_BYTES + (wave - 4) * (B_BYTES / 4) + lane * 16;
+        unsigned char* dst = Bs + bbuf_w * B_BYTES + (wave - 4) * (B_BYTES / 4);
 #pragma unroll
-      for (int k = 0; k < TPS; ++k) {
-        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(((p.tap[TPS * g + k] >> 16) * (int)p.w_st + c0) * 4);
+        for (int j = 0; j < B_BYTES / 4 / 1024; ++j)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 1024), (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                      // barrier_keep<A_IT> counts on the halo loads being issued AFTER these
+      } else {
 #pragma unroll
-        for (int j = 0; j < B_IT; ++j)
-          if (!(TG_ABL & 16) || j < B_IT / 2) rb[k * B_IT + j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_voff, so + j * b_pass, 0);
+        for (int k = 0; k < TPS; ++k) {
+          const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(((p.tap[TPS * g + k] >> 16) * (int)p.w_st + c0) * 4);
+#pragma unroll
+          for (int j = 0; j < B_IT; ++j)
+            if (!(TG_ABL & 16) || j < B_IT / 2) rb[k * B_IT + j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_voff, so + j * b_pass, 0);
+        }
       }
     };
     auto sstore_b = [&](int buf) {
-      unsigned char* b = Bs + buf * B_BYTES + st_lds;
+      if constexpr (!BF16) {
+        unsigned char* b = Bs + buf * B_BYTES + st_lds;
 #pragma unroll
-      for (int k = 0; k < TPS; ++k)
+        for (int k = 0; k < TPS; ++k)
 #pragma unroll
-        for (int j = 0; j < B_IT; ++j) put(b + k * B_TAP + j * RPP * 128, rb[k * B_IT + j]);
+          for (int j = 0; j < B_IT; ++j) put(b + k * B_TAP + j * RPP * 128, rb[k * B_IT + j]);
+      }
     };
     auto flush = [&](int tt, int parity) {                      // column sums of tile tt: the four consumer slots -> one double atomic per channel
       if (lt < BN) {
@@ -805,12 +848,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
     };
     set_tile_a(t);
     set_tile_b(t);
+    gload_b(0, 0);
     gload_a(0);
     pack_a();
     sstore_a();
-    gload_b(0, 0);
     sstore_b(0);
-    __syncthreads();                                            // (P) operands of the first step are in LDS
+    barrier_keep<0>();                                          // (P) operands of the first step are in LDS
     int bbuf = 0, k_tile = 0;
     while (true) {
       const int tn = t + t_stride;
@@ -821,8 +864,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
         for (int g = 0; g < NG; ++g) {
           const bool last_g = g == NG - 1;
           const bool more = !(last_g && last_c) || has_next;
+          bool halo_in_flight = false;
           if (more) {
             if (last_g) pack_a();
+            bbuf_w = bbuf ^ 1;                                  // the other filter buffer: last read one step ago
             if (!last_g) {
               gload_b(g + 1, c * KCH);
             } else if (!last_c) {
@@ -831,21 +876,25 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
               set_tile_b(tn);
               gload_b(0, 0);
             }
-            sstore_b(bbuf ^ 1);                                 // the other filter buffer: last read one step ago
+            sstore_b(bbuf ^ 1);
             if (g == 1) {
               if (!last_c) {
                 gload_a((c + 1) * KCH);
+                halo_in_flight = true;
               } else if (has_next) {
                 set_tile_a(tn);
                 gload_a(0);
+                halo_in_flight = true;
               }
             }
           }
-          __syncthreads();                                      // (S) the consumers are done with this step
+          // (S) the consumers are done with this step; the filter fetch has landed, the halo loads (issued after it) stay in flight
+          if (halo_in_flight) barrier_keep<A_IT>();
+          else barrier_keep<0>();
           if (COLSUM && c == 0 && g == 0 && k_tile > 0) flush(t - t_stride, (k_tile - 1) & 1);
           if (last_g && more) {
             sstore_a();                                         // the ONE halo buffer: free now
-            __syncthreads();                                    // (H)
+            barrier_keep<0>();                                  // (H)
           }
           bbuf ^= 1;
         }
@@ -855,7 +904,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
       ++k_tile;
     }
     if (COLSUM) {
-      __syncthreads();                                          // (F) the consumers' last column sums are in LDS
+      barrier_keep<0>();                                        // (F) the consumers' last column sums are in LDS
       flush(t, k_tile & 1);
     }
   } else {
@@ -928,7 +977,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                   for (int ni = 0; ni < 4; ++ni)
-                    if (!(TG_ABL & 32)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);   // D[channel][pixel]: lane = pixel
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);   // D[pixel][channel]: lane = channel
               } else {
                 f32x4 a[2], b[4];
 #pragma unroll
@@ -941,7 +990,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
                   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
-                      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][e], a[mi][e], acc[mi][ni], 0, 0, 0);
+                      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
               }
             }
           }
@@ -961,114 +1010,90 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
       LSTAMP(ts3);
       sum_k += ts3 - ts2;
 #endif
-      // ---- epilogue of tile t: registers -> global.  Tiles are whole rows of whole images, so the tile's pixels are consecutive
-      // rows of the [pixels][ld_out] output.  D[channel][pixel]: lane = pixel mi*32 + col, registers 4q..4q+3 of fragment ni = the FOUR
-      // CONSECUTIVE channels ni*32 + 8q + 4*half + (0..3) -> one 16-byte store per (mi, ni, q): 32 store instructions per wave and tile
-      // (with lane = channel they were 128 dword stores, and the store tail is bound by instruction issue, not by bytes).
+      // ---- epilogue of tile t: registers -> global.  Tiles are whole rows of whole images, so the tile's pixels are consecutive rows
+      // of the [pixels][ld_out] output.  D[pixel][channel]: lane = channel ni*32 + col, register r of fragment mi = pixel
+      // mi*32 + (r & 3) + 8*(r >> 2) + 4*half, so one dword store writes two whole 128-byte lines (one per half-wave).  Measured
+      // (tools/micro/store_patterns.hip, one workgroup per CU storing such tiles): this shape and 16-byte stores of whole lines both
+      // reach ~48 B/clk/CU when few CUs store and the chip-wide ~6 TB/s when all do; 16-byte stores straight from the transposed
+      // accumulator (32 B per line and instruction) stay at 15 B/clk/CU.  Bias, the activation and the column sums are per lane.
       {
         const int n0 = (t % p.n_tiles_n) * BN;
-        uint32_t px0 = (uint32_t)((t / p.n_tiles_n) * BM + wm0 + col);
-        asm volatile("" : "+v"(px0));                             // per-tile value: keeps the address arithmetic below out of the registers during the K loop
+        uint32_t px0 = (uint32_t)((t / p.n_tiles_n) * BM + wm0 + 4 * half);
+        asm volatile("" : "+v"(px0));                             // per-tile value: keeps the 32 row offsets below out of the registers during the K loop
         const uint32_t row_bytes = (uint32_t)p.ld_out * 4u;
-        const bool wide = (p.n_store & 3) == 0;
-        auto store4 = [&](uint32_t rowoff, int n, float v0, float v1, float v2, float v3) {
-          if (TG_ABL & 1) return;
-          if (wide) {
-            const u32x4 pk = {__builtin_bit_cast(uint32_t, v0), __builtin_bit_cast(uint32_t, v1), __builtin_bit_cast(uint32_t, v2), __builtin_bit_cast(uint32_t, v3)};
-            __builtin_amdgcn_raw_buffer_store_b128(pk, rs_o, n < p.n_store ? rowoff + (uint32_t)n * 4u : OOB, 0, 0);
-          } else {
-            const float vv[4] = {v0, v1, v2, v3};
+        // address = per-lane offset (this lane's channel in the wave's first pixel row; out of range beyond n_store) + a wave-uniform
+        // scalar offset per (mi, r): four address registers instead of thirty-two
+        uint32_t ch_off[4];
+        float cs[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv[e]), rs_o, n + e < p.n_store ? rowoff + (uint32_t)(n + e) * 4u : OOB, 0, 0);
-          }
-        };
+        for (int ni = 0; ni < 4; ++ni) {
+          const int n = n0 + ni * 32 + col;
+          ch_off[ni] = n < p.n_store ? px0 * row_bytes + (uint32_t)n * 4u : OOB;
+          cs[ni] = 0.f;
+        }
+        auto pix_off = [&](int mi, int r) { return (uint32_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes; };
         if (!COLSUM) {
           // bias + activation; only y = x > 0 ? x : slope * x forms reach this kernel (none / relu / leaky relu: conv3x3_bf16_launch)
           const float slope = p.act == TG_ACT_LRELU ? p.alpha : (p.act == TG_ACT_RELU ? 0.f : 1.f);
+          float bias_v[4];
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
-            float bv[16];
+            const uint32_t bb = __builtin_amdgcn_raw_buffer_load_b32(rs_b, (uint32_t)(n0 + ni * 32 + col) * 4u, 0, 0);      // beyond n_store / no bias: 0
+            bias_v[ni] = __builtin_bit_cast(float, bb);
+          }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const u32x4 bq = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (uint32_t)(n0 + ni * 32 + 8 * q + 4 * half) * 4u, 0, 0);   // beyond n_store: 0
-              const uint32_t b0 = bq.x, b1 = bq.y, b2 = bq.z, b3 = bq.w;
-              bv[4 * q] = __builtin_bit_cast(float, b0);
-              bv[4 * q + 1] = __builtin_bit_cast(float, b1);
-              bv[4 * q + 2] = __builtin_bit_cast(float, b2);
-              bv[4 * q + 3] = __builtin_bit_cast(float, b3);
-            }
+          for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-              const uint32_t rowoff = (px0 + (uint32_t)(mi * 32)) * row_bytes;
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t off = pix_off(mi, r);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const float x = acc[mi][ni][4 * q + e] + bv[4 * q + e];
-                  v[e] = x > 0.f ? x : slope * x;
-                }
-                store4(rowoff, n0 + ni * 32 + 8 * q + 4 * half, v[0], v[1], v[2], v[3]);
+              for (int ni = 0; ni < 4; ++ni) {
+                const float x = acc[mi][ni][r] + bias_v[ni];
+                const float v = x > 0.f ? x : slope * x;
+                if (!(TG_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, ch_off[ni], off, 0);
               }
+            }
+        } else if (ym) {
+          // the multiplier act'(y) is read at the output's own addresses, one (mi, ni) fragment (16 dwords per lane) ahead of its use
+          const float slope = p.ymul_act == TG_ACT_LRELU ? p.ymul_alpha : (p.ymul_act == TG_ACT_RELU ? 0.f : 1.f);
+          uint32_t yv[2][16];
+          auto yload = [&](int f, int buf) {
+            const int mi = f >> 2, ni = f & 3;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yv[buf][r] = __builtin_amdgcn_raw_buffer_load_b32(rs_y, ch_off[ni], pix_off(mi, r), 0);
+          };
+          yload(0, 0);
+#pragma unroll
+          for (int f = 0; f < 8; ++f) {
+            const int mi = f >> 2, ni = f & 3;
+            if (f + 1 < 8) yload(f + 1, (f + 1) & 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t yb = yv[f & 1][r];
+              const float v = acc[mi][ni][r] * (__builtin_bit_cast(float, yb) > 0.f ? 1.f : slope);
+              cs[ni] += v;
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, ch_off[ni], pix_off(mi, r), 0);
             }
           }
         } else {
-          if (ym) {
-            // the multiplier act'(y) is read at the output's own addresses, one fragment (4 x 16 bytes per lane) ahead of its use
-            const float slope = p.ymul_act == TG_ACT_LRELU ? p.ymul_alpha : (p.ymul_act == TG_ACT_RELU ? 0.f : 1.f);
-            u32x4 yv[2][4];
-            auto yload = [&](int f, int buf) {
-              const int ni = f >> 1, mi = f & 1;
-              const uint32_t rowoff = (px0 + (uint32_t)(mi * 32)) * row_bytes;
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int n = n0 + ni * 32 + 8 * q + 4 * half;
-                yv[buf][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, n < p.n_store ? rowoff + (uint32_t)n * 4u : OOB, 0, 0);
-              }
-            };
-            yload(0, 0);
-#pragma unroll
-            for (int f = 0; f < 8; ++f) {
-              const int ni = f >> 1, mi = f & 1;
-              if (f + 1 < 8) yload(f + 1, (f + 1) & 1);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const u32x4 yq = yv[f & 1][q];
-                const uint32_t y0 = yq.x, y1 = yq.y, y2 = yq.z, y3 = yq.w;     // scalars first (ext-vector element bit-casts: see the symmetric kernel)
-                const float yy[4] = {__builtin_bit_cast(float, y0), __builtin_bit_cast(float, y1), __builtin_bit_cast(float, y2), __builtin_bit_cast(float, y3)};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  acc[mi][ni][4 * q + e] *= yy[e] > 0.f ? 1.f : slope;
-              }
-            }
-          }
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-              const uint32_t rowoff = (px0 + (uint32_t)(mi * 32)) * row_bytes;
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                store4(rowoff, n0 + ni * 32 + 8 * q + 4 * half, acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
-            }
-            // column sums of this wave's 64 pixels: two pixels per lane, then across the 32 lanes of each half (DPP butterfly inside the
-            // 16-lane rows, row_bcast15 into rows 1 and 3); lanes 31 / 63 write their half's 4 x 4 channels of fragment ni
-            float cs[16];
+          for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              float v = acc[0][ni][r] + acc[1][ni][r];
-              v = dpp_add<0xB1>(v);                              // quad_perm [1,0,3,2]
-              v = dpp_add<0x4E>(v);                              // quad_perm [2,3,0,1]
-              v = dpp_add<0x141>(v);                             // row_half_mirror
-              v = dpp_add<0x140>(v);                             // row_mirror
-              cs[r] = dpp_add<0x142, 0xA>(v);                    // row_bcast15 into rows 1, 3
-            }
-            if (col == 31) {
-              float* rp = red + ((k_tile & 1) * 4 + wave) * BN + ni * 32 + 4 * half;
+              const uint32_t off = pix_off(mi, r);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(rp + 8 * q) = make_float4(cs[4 * q], cs[4 * q + 1], cs[4 * q + 2], cs[4 * q + 3]);
+              for (int ni = 0; ni < 4; ++ni) {
+                const float v = acc[mi][ni][r];
+                cs[ni] += v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, ch_off[ni], off, 0);
+              }
             }
+        }
+        if (COLSUM) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const float o = __shfl_xor(cs[ni], 32);
+            if (half == 0) red[((k_tile & 1) * 4 + wave) * BN + ni * 32 + col] = cs[ni] + o;
           }
         }
       }
@@ -1119,10 +1144,42 @@ void launch(ConvParams& p, hipStream_t s) {
 int g_force_bm = 0, g_dbg = 0, g_stagger = 0;
 const bool g_symmetric = getenv("TG_CONV3X3_SYMMETRIC") != nullptr;      // A/B: the symmetric (non role-specialised) 256-pixel kernel
 const int g_env_loaded = ([] { if (const char* e = getenv("TG_CONV3X3_BM")) g_force_bm = atoi(e); if (const char* e = getenv("TG_CONV3X3_DBG")) g_dbg = atoi(e); if (const char* e = getenv("TG_CONV3X3_STAGGER")) g_stagger = atoi(e); return 0; })();
-const bool g_pipe_colsum = getenv("TG_CONV3X3_PIPE_COLSUM") != nullptr;
 const bool g_staged = getenv("TG_CONV3X3_STAGED") != nullptr;            // A/B: one tile per workgroup, LDS-staged epilogue (conv3x3_ws_kernel)
 const bool g_disabled = getenv("TG_NO_CONV3X3_BF16") != nullptr;     // A/B switches, read once at library load
 const bool g_disabled_f32 = getenv("TG_NO_CONV3X3_F32") != nullptr;
+
+// Scratch for the packed bf16 filters of conv3x3_pipe_kernel: a ring of four 8 MB device buffers, allocated at the first launch that wants one
+// (never inside a stream capture — such a launch takes the staged kernel instead) and kept for the life of the process.  A launch packs
+// into the next slot and the convolution that follows on the same stream reads it; launches of this path are issued from one host thread
+// and are stream-ordered with each other (the package's single compute stream, or the linear graph captured from it), so a slot is
+// rewritten only three convolutions after the one that read it.
+constexpr size_t PACK_SLOT_BYTES = 8u << 20;
+constexpr int PACK_SLOTS = 4;
+void* g_pack[PACK_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+int g_pack_dev = -1, g_pack_next = 0;
+bool g_pack_failed = false;
+
+void* pack_slot(size_t need, hipStream_t s) {
+  if (need > PACK_SLOT_BYTES || g_pack_failed) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (g_pack_dev < 0) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    for (int i = 0; i < PACK_SLOTS; ++i)
+      if (hipMalloc(&g_pack[i], PACK_SLOT_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        for (int j = 0; j < i; ++j) (void)hipFree(g_pack[j]);
+        g_pack_failed = true;
+        return nullptr;
+      }
+    g_pack_dev = dev;
+  }
+  if (dev != g_pack_dev) return nullptr;
+  void* r = g_pack[g_pack_next];
+  g_pack_next = (g_pack_next + 1) % PACK_SLOTS;
+  return r;
+}
 
 int g_policy = 0;                      // tg_conv3x3_policy: 0 = where it pays (below), 1 = wherever it applies, 2 = never
 long g_launches = 0;
@@ -1191,9 +1248,18 @@ int conv3x3_bf16_launch(const tg_igemm_desc* d, const float* in, const float* w,
   p.in_bytes = in_bytes; p.w_bytes = w_bytes; p.out_bytes = out_bytes;
   ++g_launches;
   const auto simple = [](int a) { return a == TG_ACT_NONE || a == TG_ACT_LRELU || a == TG_ACT_RELU; };
-  // measured (N = 250, bf16): without column sums the pipelined form is 8-13 % faster on the 32x32 and 16x16/128-channel layers and 3 % slower
-  // on conv2_2; with them (32-lane register reductions in the epilogue) it is 5-15 % slower than the staged form -> TG_CONV3X3_PIPE_COLSUM opts in
-  if (bm == 256 && !g_staged && (!g_symmetric || !bf16) && simple(d->act) && (ymul == nullptr || simple(ymul_act)) && (colsum == nullptr || g_pipe_colsum)) {
+  // measured (N = 250 images, conv1_2 / conv2_1 / conv2_2; staged -> pipelined): bf16 585 / 597 / 809 -> 869 / 739 / 961 TFLOP/s, with column sums
+  // 616 / 632 / 852 -> 794 / 672 / 883, exact fp32 119 / 128 / 138 -> 123 / 132 / 141
+  bool pipe = bm == 256 && !g_staged && (!g_symmetric || !bf16) && simple(d->act) && (ymul == nullptr || simple(ymul_act));
+  p.wpk = nullptr;
+  if (pipe && bf16) {
+    const int nchunks = d->ld_in / KC;
+    const int total = p.n_tiles_n * nchunks * 9 * 1024;        // 16-byte chunks of the packed filter
+    p.wpk = pack_slot((size_t)total * 16, s);
+    if (p.wpk == nullptr) pipe = false;
+    else hipLaunchKernelGGL(filter_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p, nchunks, total);
+  }
+  if (pipe) {
     if (d->w_in == 16) launch_pipe<16>(p, s);
     else if (d->w_in == 32) launch_pipe<32>(p, s);
     else launch_pipe<64>(p, s);
