@@ -914,10 +914,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias ? p.bias : p.w), 0, p.bias ? (uint32_t)p.n_store * 4u : 0u, 0x00020000);
     const bool ym = COLSUM && p.ymul != nullptr;
     const int wm0 = wave * 64;
+    // Which pixel of its 32-pixel fragment lane `col` multiplies.  A ds_read_b128 is served in four groups of 16 lanes ({0-3, 12-15, 20-27},
+    // {4-11, 16-19, 28-31} and the same + 32), conflict-free when the 16 halo rows of a group differ mod 16 (128-byte rows, the swizzle
+    // key is row bits 1..3).  W = 32 / 64: the 32 pixels are consecutive in one halo row -> they do.  W = 16: lanes 16-31 sit in the
+    // NEXT image row, 18 halo rows further on, and raster order makes rows 12, 13 mod 16 collide with the first row's (measured: 23 % of
+    // the LDS cycles were conflicts); rotating the second row's pixels by two (lane 16 + i takes x = (i - 2) mod 16) restores
+    // row = base + i mod 16.  The epilogue stores through the same map (frag_pixel).
+    const int pc = (W == 16 && col >= 16) ? 16 + ((col - 18) & 15) : col;
     int a_hp[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const int r = wm0 + mi * 32 + col;
+      const int r = wm0 + mi * 32 + pc;
       const int ty = r / W, tx = r - ty * W;
       a_hp[mi] = (ty + 1) * HW_ + tx + 1;
     }
@@ -1031,7 +1038,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
           ch_off[ni] = n < p.n_store ? px0 * row_bytes + (uint32_t)n * 4u : OOB;
           cs[ni] = 0.f;
         }
-        auto pix_off = [&](int mi, int r) { return (uint32_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes; };
+        // pixel of fragment row (r & 3) + 8*(r >> 2) + 4*half, less the 4*half that px0 carries; W = 16: rows 16.. are rotated (see pc
+        // above) and for r = 8, 9 the lower half-wave's pixels wrap around to the end of the image row (+16: wrap16)
+        auto pix_off = [&](int mi, int r) {
+          const int i = (W == 16 && r >= 8) ? 16 + 8 * ((r >> 2) - 2) + (r & 3) - 2 : (r & 3) + 8 * (r >> 2);
+          return (uint32_t)(mi * 32 + i) * row_bytes;
+        };
+        const uint32_t wrap16 = (W == 16 && half == 0) ? 16u * row_bytes : 0u;
+        auto lane_off = [&](int ni, int r) { return (W == 16 && (r == 8 || r == 9)) ? ch_off[ni] + wrap16 : ch_off[ni]; };
         if (!COLSUM) {
           // bias + activation; only y = x > 0 ? x : slope * x forms reach this kernel (none / relu / leaky relu: conv3x3_bf16_launch)
           const float slope = p.act == TG_ACT_LRELU ? p.alpha : (p.act == TG_ACT_RELU ? 0.f : 1.f);
@@ -1050,7 +1064,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
               for (int ni = 0; ni < 4; ++ni) {
                 const float x = acc[mi][ni][r] + bias_v[ni];
                 const float v = x > 0.f ? x : slope * x;
-                if (!(TG_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, ch_off[ni], off, 0);
+                if (!(TG_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, lane_off(ni, r), off, 0);
               }
             }
         } else if (ym) {
@@ -1060,7 +1074,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
           auto yload = [&](int f, int buf) {
             const int mi = f >> 2, ni = f & 3;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) yv[buf][r] = __builtin_amdgcn_raw_buffer_load_b32(rs_y, ch_off[ni], pix_off(mi, r), 0);
+            for (int r = 0; r < 16; ++r) yv[buf][r] = __builtin_amdgcn_raw_buffer_load_b32(rs_y, lane_off(ni, r), pix_off(mi, r), 0);
           };
           yload(0, 0);
 #pragma unroll
@@ -1072,7 +1086,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
               const uint32_t yb = yv[f & 1][r];
               const float v = acc[mi][ni][r] * (__builtin_bit_cast(float, yb) > 0.f ? 1.f : slope);
               cs[ni] += v;
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, ch_off[ni], pix_off(mi, r), 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, lane_off(ni, r), pix_off(mi, r), 0);
             }
           }
         } else {
@@ -1085,7 +1099,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
               for (int ni = 0; ni < 4; ++ni) {
                 const float v = acc[mi][ni][r];
                 cs[ni] += v;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, ch_off[ni], off, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, lane_off(ni, r), off, 0);
               }
             }
         }

@@ -383,8 +383,11 @@ def test_input_gradient_fused_with_mobn_backward_statistics(prec, segs, h, cin, 
     sums = torch.zeros(2 * len(segs) * cin, device='cuda')
     descs = geom.conv_dgrad(n, h, w_, cin, co_p, 3, 1, 'SAME')
     assert len(descs) == 1
+    was, halo0 = lib.call('tg_conv3x3_policy', 1), lib.call('tg_conv3x3_launches')        # the halo kernel wherever the layer applies
     lib.call('tg_igemm_actsum_' + prec, descs[0], lib.ptr(dd), lib.ptr(wd), lib.ptr(yd), lib.ACT['lrelu'], 0.2, lib.ptr(td), sa, len(segs),
              lib.ptr(sums), 0, st())
+    lib.call('tg_conv3x3_policy', was)
+    assert lib.call('tg_conv3x3_launches') - halo0 == int(h in (16, 32))
     scale = np.abs(dpre).max() * np.abs(wt).max() * 9 * cout
     assert np.abs(td.cpu().numpy() - t_ref).max() <= 3e-5 * scale
     dxd, dbd = torch.full((n, h, w_, cin), 7.0, device='cuda'), torch.full((cin,), 7.0, device='cuda')
@@ -424,3 +427,44 @@ def test_maxpool_backward_fused_with_mobn_backward_statistics():
     lib.call('tg_mobn_center_f32', lib.ptr(td), c, lib.ptr(dxd), c, n * h * h, c, sa, len(segs), lib.ptr(sums), 8, lib.ptr(dbd), st())
     np.testing.assert_allclose(dxd.cpu().numpy(), dx_ref, rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(dbd.cpu().numpy(), t_ref.sum(axis=(0, 1, 2)), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("prec", ['f32', 'bf16'])
+@pytest.mark.parametrize("hw,cin,cout,n,segs", [(16, 128, 128, 300, [100, 200]), (32, 64, 256, 150, [150])])
+def test_halo_kernel_walks_several_tiles_per_workgroup(prec, hw, cin, cout, n, segs):
+    """csrc/conv3x3_bf16.hip, persistent tile-pipelined form: with more tiles than compute units a workgroup walks several tiles (operands of
+    the next tile fetched during the current one, column sums handed to the loader waves tile by tile).  300 images of 16x16 are 300 tiles,
+    150 of 32x32 with 256 output channels 1 200.  Checked against the generic implicit GEMM of the same library (itself checked against the
+    oracle above and in test_gpu_igemm.py) on the forward pass with bias + leaky relu, the forward pass with per-application column sums,
+    and the input gradient with the activation-gradient multiplier and column sums; tolerance = fp32 accumulation order."""
+    from tg import geom
+    lib = _lib()
+    rng = np.random.default_rng(11)
+    x = dev(rng.standard_normal((n, hw, hw, cin)))
+    w_oti = dev(rng.standard_normal((cout, 9, cin)) * 0.1)
+    w_hwio = dev(rng.standard_normal((9, cin, cout)) * 0.1)
+    bias = dev(rng.standard_normal(cout))
+    dy = dev(rng.standard_normal((n, hw, hw, cout)))
+    sa = (C.c_int32 * len(segs))(*[s * hw * hw for s in segs])
+    d_act, d_lin = geom.conv_fwd(n, hw, hw, cin, cout, 3, 1, 'SAME', act='lrelu'), geom.conv_fwd(n, hw, hw, cin, cout, 3, 1, 'SAME')
+    d_bwd = geom.conv_dgrad(n, hw, hw, cin, cout, 3, 1, 'SAME')[0]
+    outs = {}
+    for policy in (1, 2):                             # 1: the halo kernel wherever it applies, 2: never
+        was, halo0 = lib.call('tg_conv3x3_policy', policy), lib.call('tg_conv3x3_launches')
+        y1 = torch.full((n, hw, hw, cout), 7.0, device='cuda')
+        lib.call('tg_igemm_' + prec, d_act, lib.ptr(x), lib.ptr(w_oti), lib.ptr(bias), lib.ptr(y1), st())
+        y2, s2 = torch.full((n, hw, hw, cout), 7.0, device='cuda'), torch.zeros(2 * len(segs) * cout, device='cuda')
+        lib.call('tg_igemm_colsum_' + prec, d_lin, lib.ptr(x), lib.ptr(w_oti), lib.ptr(y2), sa, len(segs), lib.ptr(s2), 0, st())
+        g3, s3 = torch.full((n, hw, hw, cin), 7.0, device='cuda'), torch.zeros(2 * len(segs) * cin, device='cuda')
+        lib.call('tg_igemm_actsum_' + prec, d_bwd, lib.ptr(dy), lib.ptr(w_hwio), lib.ptr(x), lib.ACT['lrelu'], 0.2, lib.ptr(g3), sa, len(segs),
+                 lib.ptr(s3), 0, st())                # the halo kernel needs 128 | output channels: the input gradient of the second case stays generic
+        lib.call('tg_conv3x3_policy', was)
+        assert lib.call('tg_conv3x3_launches') - halo0 == (2 + int(cin % 128 == 0) if policy == 1 else 0)
+        outs[policy] = [t.cpu().numpy() for t in (y1, y2, s2, g3, s3)]
+    scale = float(x.abs().max()) * 0.5 * 9 * cin
+    scale_g = float(dy.abs().max()) * 0.5 * 9 * cout
+    for i, sc in ((0, scale), (1, scale), (3, scale_g)):
+        assert np.abs(outs[1][i] - outs[2][i]).max() <= 3e-5 * sc, i
+    sums = lambda a: np.frombuffer(a.tobytes(), np.float64)              # the column sums are doubles in a float32 tensor's storage
+    np.testing.assert_allclose(sums(outs[1][2]), sums(outs[2][2]), rtol=1e-5, atol=1e-6 * scale * segs[-1] * hw * hw)
+    np.testing.assert_allclose(sums(outs[1][4]), sums(outs[2][4]), rtol=1e-5, atol=1e-6 * scale_g * segs[-1] * hw * hw)
