@@ -142,28 +142,25 @@ def cpu_baseline(warmup=1, timed=3):
                        "each), NumPy/BLAS fp32 oracle (TF1 unobtainable)" % (warmup, timed, med))
 
 
-def _sha256(path):
-    import hashlib
-    return hashlib.sha256(open(path, 'rb').read()).hexdigest()
-
-
 def measured_traffic():
     """HBM bytes of the dominant launch from the PMC passes stored under profiles/ (rocprofv3 cannot run inside this process).  The
-    record names the kernel source it was collected for (sha256 of csrc/igemm.hip): for any other source the figure is stale and
-    `traffic` is null."""
+    record names the kernel sources it was collected for (sha256 of csrc/igemm.hip + csrc/conv3x3_bf16.hip): for any other source the
+    figure is stale and `traffic` is null."""
     for name in ('r02_traffic.json', 'r01_traffic.json'):
         tfile = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(tfile):
             continue
         rec = json.load(open(tfile))
         tj = rec['dominant_launch']
-        want = rec.get('igemm_hip_sha256')
-        have = _sha256(os.path.join(PKG, 'csrc', 'igemm.hip'))
+        want = rec.get('kernel_sources_sha256')
+        csrc = os.path.join(PKG, 'csrc')
+        import hashlib
+        have = hashlib.sha256(open(os.path.join(csrc, 'igemm.hip'), 'rb').read() + open(os.path.join(csrc, 'conv3x3_bf16.hip'), 'rb').read()).hexdigest()
         if want != have:
-            return None, dict(stale='profiles/%s was collected for another csrc/igemm.hip (%s...), this build has %s...: re-run '
-                                    'tools/pmc_traffic.sh' % (name, str(want)[:12], have[:12]))
+            return None, dict(stale='profiles/%s was collected for other kernel sources (%s...), this build has %s...: re-run '
+                                    'tools/pmc_traffic.sh + tools/make_traffic_json.py' % (name, str(want)[:12], have[:12]))
         return tj['traffic_bytes_corrected'], dict(
-            algorithmic_bytes_per_launch=tj['algorithmic_bytes'], kernel=tj['kernel'], igemm_hip_sha256=have,
+            algorithmic_bytes_per_launch=tj['algorithmic_bytes'], kernel=tj['kernel'], kernel_sources_sha256=have,
             source='profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950-corrected)' % name)
     return None, None
 
@@ -284,7 +281,7 @@ def main():
     achieved = fl['executed_igemm'] / (ig['ms_per_iter'] * 1e-3) / 1e12
     n_conv_launches = (conv_n['igemm_f32'] + conv_n['wgrad_f32']) / args.prof_iters
     traffic, traffic_detail = measured_traffic()
-    roofline = dict(bound="mfma", kernel="classifier 3x3 conv path: igemm_f32_kernel (fwd + input grad) + wgrad_f32_kernel",
+    roofline = dict(bound="mfma", kernel="classifier 3x3 conv path: conv3x3_pipe_kernel / igemm_f32_kernel (fwd + input grad) + wgrad_f32_kernel",
                     achieved=round(conv_tf, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(conv_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                     traffic=traffic, traffic_detail=traffic_detail, launches_per_step=n_conv_launches,
                     avg_launch_ms=round((conv_ms['igemm_f32'] + conv_ms['wgrad_f32']) / max(n_conv_launches, 1), 5),

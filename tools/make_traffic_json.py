@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """After tools/pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, separate, no trace domains): write the HBM-traffic
-record bench.py's `roofline.traffic` is read from.  The record carries the sha256 of csrc/igemm.hip it was collected for; bench.py
-reports traffic = null for any other source (a stale figure is worse than none).
+record bench.py's `roofline.traffic` is read from.  The record carries the sha256 of the kernel sources it was collected for (csrc/igemm.hip +
+csrc/conv3x3_bf16.hip, concatenated); bench.py reports traffic = null for any other source (a stale figure is worse than none).
 
     python tools/make_traffic_json.py [gpurun_out/traffic] [round tag] > profiles/<round>_traffic.json
 """
@@ -42,19 +42,26 @@ def entry(match, wgs):
 
 M, C = 250 * 32 * 32, 128
 alg_fwd = 4 * (M * C + M * C + C * 9 * C)                       # input + output + filter, fp32
-dom = entry('igemm_f32_kernel<64, 64, 2, 2, true, false>', 8000)
+dom = entry('conv3x3_pipe_kernel<32, true, false>', 256)
+CSRC = os.path.join(ROOT, 'tensorflow-implementation-of-triple-gan_amd', 'csrc')
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace domains) on `python3 bench.py --steps 3 --warmup 2 --no-graph`, "
               "round %s, one MI355X; tools/pmc_traffic.sh + tools/make_traffic_json.py" % tag,
     "units": "counter values are KB; gfx950 correction of MI355X_MICROARCH.md §HBM: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced streams -> x2; WRITE_SIZE exact",
-    "igemm_hip_sha256": hashlib.sha256(open(os.path.join(ROOT, 'tensorflow-implementation-of-triple-gan_amd', 'csrc', 'igemm.hip'), 'rb').read()).hexdigest(),
+    "kernel_sources_sha256": hashlib.sha256(open(os.path.join(CSRC, 'igemm.hip'), 'rb').read() + open(os.path.join(CSRC, 'conv3x3_bf16.hip'), 'rb').read()).hexdigest(),
 }
 if dom:
     n_act = 12.0 / 30.0                                          # share of tg_igemm_actsum launches (they also read the producing layer's activation)
-    dom.update(kernel="igemm_f32_kernel<64,64,2,2,COLSUM=true>, 8000 workgroups, 250 images 32x32x128 -> 128: classifier conv1_2 / conv1_3 forward with fused "
-                      "mean-only-BN column sums and their input gradients with the fused activation derivative + column sums (tg_igemm_actsum)",
+    dom.update(kernel="conv3x3_pipe_kernel<W=32,COLSUM,fp32>, 256 persistent workgroups walking 1000 tiles, 250 images 32x32x128 -> 128: classifier conv1_2 / conv1_3 "
+                      "forward with fused mean-only-BN column sums and their input gradients with the fused activation derivative + column sums (tg_igemm_actsum)",
                algorithmic_bytes=int(alg_fwd + n_act * 4 * M * C))
     out["dominant_launch"] = dom
+gen = entry('igemm_f32_kernel<64, 64, 2, 2, true, false>', 4160)
+if gen:
+    gen.update(kernel="igemm_f32_kernel<64,64,2,2,COLSUM=true>, 4160 workgroups: the same layers on the D-update's 130 images (520 halo tiles would leave the third "
+                      "round of one workgroup per CU nearly empty: tg_conv3x3_policy routes them to the generic implicit GEMM)",
+               algorithmic_bytes=int(4 * (2 * 130 * 1024 * C + C * 9 * C)))
+    out["generic_launch"] = gen
 wg = entry('wgrad_f32_kernel<128, 128, 2, 2, 1, false>', 504)
 if wg:
     wg.update(kernel="wgrad_f32_kernel<128,128,2,2,1>, 504 workgroups: filter gradient of conv1_2 / conv1_3 (9 taps x 56 pixel splits)",
