@@ -75,8 +75,8 @@ def make_config(name='stress64'):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', choices=sorted(SHAPES), default='stress64')
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=5)
     args = ap.parse_args()
     import torch
     from tg import lib
