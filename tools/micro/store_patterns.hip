@@ -4,7 +4,7 @@
 //   1: 16 B per lane, lane = pixel: 32 pixels x (2 x 16 B adjacent) per instruction                — D[channel][pixel] accumulators as they stand
 //   2:  4 B per lane, lanes 0-31 one 128-B line, lanes 32-63 another                              — D[pixel][channel] accumulators as they stand
 //   3: 16 B per lane, 8 lanes (4 quads x 2 halves) per pixel: 8 pixels x 128 B per instruction     — after a 4 x 4 lane/register transpose
-// Build: hipcc -O3 --offload-arch=gfx950 store_patterns.hip -o store_patterns ; run: ./store_patterns [workgroups]
+// Build: hipcc -O3 --offload-arch=gfx950 -w store_patterns.hip -o store_patterns (the binary is git-ignored); run on the GPU box: tools/micro/store_patterns [workgroups]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
