@@ -1209,7 +1209,8 @@ int pick_bm(const tg_igemm_desc* d) {
 
 namespace tg {
 
-bool conv3x3_bf16_applicable(const tg_igemm_desc* d, int n_desc, const int32_t* seg_rows, int nseg, bool bf16) {
+// the layer has the kernel's shape (independent of how many images the launch holds)
+static bool conv3x3_fits(const tg_igemm_desc* d, int n_desc, const int32_t* seg_rows, int nseg, bool bf16) {
   if ((bf16 ? g_disabled : g_disabled_f32) || g_policy == 2) return false;
   if (!bf16 && d->h_in % (256 / (d->w_in > 0 ? d->w_in : 1))) return false;          // the fp32 form exists for the 256-pixel tile only
   if (n_desc != 1 || d->n_taps != 9 || d->n_group != 0) return false;
@@ -1228,18 +1229,40 @@ bool conv3x3_bf16_applicable(const tg_igemm_desc* d, int n_desc, const int32_t* 
   const int per_img = d->h_in * d->w_in;
   for (int i = 0; i < nseg; ++i)
     if (seg_rows[i] % per_img) return false;                  // applications are whole images: a tile never straddles a segment
-  if (g_policy == 0) {
-    // One workgroup per CU (141-150 KB of LDS), so the launch runs in ceil(tiles / CUs) rounds and the last one may be nearly
-    // empty: 130 images of 32x32 are 520 tiles = 3 rounds on 256 CUs for 2.03 rounds of work.  The generic implicit GEMM (8 000
-    // small workgroups) has no such step, so the halo form is taken only where its per-tile advantage (measured, full rounds:
-    // 1.07x with fp32 operands, 1.9x with bf16 ones) survives the quantisation.
-    const int bm = bf16 ? pick_bm(d) : 256;
-    const long slots = (long)compute_units() * (bm == 128 ? 2 : 1);
-    const long tiles = (long)d->n_img * per_img / bm * (d->c_out / BN);
-    const long rounds = (tiles + slots - 1) / slots;
-    if ((double)tiles / (double)(rounds * slots) * (bf16 ? 1.8 : 1.07) < 1.0) return false;
-  }
   return true;
+}
+
+// One workgroup per CU (141-150 KB of LDS), so a launch runs in ceil(tiles / CUs) rounds and the last one may be nearly empty: 130 images
+// of 32x32 are 520 tiles = 3 rounds on 256 CUs for 2.03 rounds of work.  The generic implicit GEMM (thousands of small workgroups) has no
+// such step, so the halo form is taken only where its per-tile advantage (measured on full rounds: 1.07x with fp32 operands, 1.8x with
+// bf16 ones) survives the quantisation.
+static long conv3x3_slots(const tg_igemm_desc* d, bool bf16) { return (long)compute_units() * ((bf16 ? pick_bm(d) : 256) == 128 ? 2 : 1); }
+static long conv3x3_tiles_per_image(const tg_igemm_desc* d, bool bf16) { return (long)d->h_in * d->w_in / (bf16 ? pick_bm(d) : 256) * (d->c_out / BN); }
+
+static bool conv3x3_pays(const tg_igemm_desc* d, bool bf16, int n_img) {
+  if (g_policy != 0) return true;
+  const long slots = conv3x3_slots(d, bf16), tiles = conv3x3_tiles_per_image(d, bf16) * n_img;
+  const long rounds = (tiles + slots - 1) / slots;
+  return (double)tiles / (double)(rounds * slots) * (bf16 ? 1.8 : 1.07) >= 1.0;
+}
+
+bool conv3x3_bf16_applicable(const tg_igemm_desc* d, int n_desc, const int32_t* seg_rows, int nseg, bool bf16) {
+  return conv3x3_fits(d, n_desc, seg_rows, nseg, bf16) && conv3x3_pays(d, bf16, d->n_img);
+}
+
+// A launch of the right shape whose last round is less than 90 % full: the number of LEADING images that make whole rounds — they go to
+// the halo kernel, the few images left to the generic one (igemm_impl splits the launch; 130 images of 32x32: 128 + 2).  0: no such
+// split (rounds full enough, too few images for one round, or the whole-round prefix is less than 60 % of the launch).
+int conv3x3_bf16_split_images(const tg_igemm_desc* d, int n_desc, const int32_t* seg_rows, int nseg, bool bf16) {
+  if (g_policy != 0 || !conv3x3_fits(d, n_desc, seg_rows, nseg, bf16)) return 0;
+  const long slots = conv3x3_slots(d, bf16), tpi = conv3x3_tiles_per_image(d, bf16);
+  const long tiles = tpi * d->n_img, rounds = (tiles + slots - 1) / slots;
+  if (tiles * 10 >= rounds * slots * 9) return 0;
+  const long full = tiles / slots;                            // whole rounds in the launch
+  if (full < 1) return 0;
+  const long head = full * slots / tpi;                       // images in them (rounded down: the head's last round may miss a few tiles)
+  if (head < 1 || head >= d->n_img || head * 10 < (long)d->n_img * 6 || !conv3x3_pays(d, bf16, (int)head)) return 0;
+  return (int)head;
 }
 
 int conv3x3_bf16_launch(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, double* colsum,

@@ -704,6 +704,34 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
                       float ymul_alpha = 0.f) {
   TG_REQUIRE(descs && n_desc >= 1 && n_desc <= MAX_SUB, "igemm: n_desc=%d out of range", n_desc);
   TG_REQUIRE(in && w && out, "igemm: null buffer");
+  // A 3x3 layer of the halo kernel's shape whose launch does not fill whole rounds of one workgroup per CU (conv3x3_bf16.hip): the leading
+  // images that do go to that kernel, the few left over to the generic one — two launches over disjoint image ranges of the same buffers
+  // (the column sums of both accumulate into the same per-segment accumulators).
+  if (const int head = tg::conv3x3_bf16_split_images(descs, n_desc, seg_rows, colsum ? nseg : 0, bf16)) {
+    tg_igemm_desc dh = descs[0], dt = descs[0];
+    dh.n_img = head;
+    dt.n_img = descs[0].n_img - head;
+    const int64_t per_img = (int64_t)descs[0].h_in * descs[0].w_in;
+    int32_t seg_h[8], seg_t[8];
+    int nh = 0, nt = 0, k0 = 0;
+    if (colsum) {
+      int64_t left = (int64_t)head * per_img;                   // rows of the head still to hand out
+      for (int i = 0; i < nseg; ++i) {
+        const int64_t r = seg_rows[i], take = r < left ? r : left;
+        if (take > 0) seg_h[nh++] = (int32_t)take;
+        if (r - take > 0) {
+          if (nt == 0) k0 = i;
+          seg_t[nt++] = (int32_t)(r - take);
+        }
+        left -= take;
+      }
+    }
+    int rc = igemm_impl(&dh, 1, in, w, bias, out, stream, colsum, colsum ? seg_h : nullptr, nh, bf16, ymul, ymul_act, ymul_alpha);
+    if (rc != TG_OK) return rc;
+    const int64_t o_in = (int64_t)head * per_img * descs[0].ld_in, o_out = (int64_t)head * per_img * descs[0].ld_out;
+    return igemm_impl(&dt, 1, in + o_in, w, bias, out + o_out, stream, colsum ? colsum + (int64_t)k0 * descs[0].c_out : nullptr, colsum ? seg_t : nullptr, nt, bf16,
+                      ymul ? ymul + o_out : nullptr, ymul_act, ymul_alpha);
+  }
   IgemmParams p;
   p.in = in; p.w = w; p.bias = bias; p.out = out; p.n_sub = n_desc;
   p.colsum = colsum; p.nseg = nseg;

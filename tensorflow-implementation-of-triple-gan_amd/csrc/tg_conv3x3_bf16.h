@@ -9,6 +9,8 @@ namespace tg {
 // 9 taps of a 3x3 window, stride 1, output grid = input grid (SAME), width 16 / 32 / 64 with 256 / width dividing the height, 64 | ld_in,
 // 128 | c_out, segments of whole images
 bool conv3x3_bf16_applicable(const tg_igemm_desc* d, int n_desc, const int32_t* seg_rows, int nseg, bool bf16);   // bf16 = false: the exact-fp32 form (32 | ld_in)
+// > 0: the launch has the kernel's shape but does not fill whole rounds of one workgroup per CU; that many leading images do
+int conv3x3_bf16_split_images(const tg_igemm_desc* d, int n_desc, const int32_t* seg_rows, int nseg, bool bf16);
 int conv3x3_bf16_launch(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, double* colsum,
                         const int32_t* seg_rows, int nseg, const float* ymul, int ymul_act, float ymul_alpha, uint32_t in_bytes, uint32_t w_bytes,
                         uint32_t out_bytes, hipStream_t s, bool bf16);

@@ -468,3 +468,43 @@ def test_halo_kernel_walks_several_tiles_per_workgroup(prec, hw, cin, cout, n, s
     sums = lambda a: np.frombuffer(a.tobytes(), np.float64)              # the column sums are doubles in a float32 tensor's storage
     np.testing.assert_allclose(sums(outs[1][2]), sums(outs[2][2]), rtol=1e-5, atol=1e-6 * scale * segs[-1] * hw * hw)
     np.testing.assert_allclose(sums(outs[1][4]), sums(outs[2][4]), rtol=1e-5, atol=1e-6 * scale_g * segs[-1] * hw * hw)
+
+
+@pytest.mark.parametrize("prec", ['f32', 'bf16'])
+@pytest.mark.parametrize("segs", [[50, 80], [129, 1], [130]])
+def test_halo_kernel_takes_the_whole_rounds_of_a_launch_and_the_generic_kernel_the_rest(prec, segs):
+    """Default routing (tg_conv3x3_policy 0): 130 images of 32x32x128 -> 128 are 520 halo tiles = 2.03 rounds of one workgroup per CU; the
+    launch is split — 128 leading images (512 tiles) on the halo kernel, 2 on the generic implicit GEMM — over disjoint image ranges of the
+    same buffers, the column sums of both parts landing in the same per-application accumulators, also when an application boundary falls
+    inside the head ([50, 80]) or inside the tail ([129, 1]).  Compared with the unsplit generic launch (policy 2)."""
+    from tg import geom
+    lib = _lib()
+    n, hw, cin, cout = sum(segs), 32, 128, 128
+    rng = np.random.default_rng(12)
+    x = dev(rng.standard_normal((n, hw, hw, cin)))
+    w_oti = dev(rng.standard_normal((cout, 9, cin)) * 0.1)
+    w_hwio = dev(rng.standard_normal((9, cin, cout)) * 0.1)
+    bias = dev(rng.standard_normal(cout))
+    dy = dev(rng.standard_normal((n, hw, hw, cout)))
+    sa = (C.c_int32 * len(segs))(*[s * hw * hw for s in segs])
+    d_act, d_lin = geom.conv_fwd(n, hw, hw, cin, cout, 3, 1, 'SAME', act='lrelu'), geom.conv_fwd(n, hw, hw, cin, cout, 3, 1, 'SAME')
+    d_bwd = geom.conv_dgrad(n, hw, hw, cin, cout, 3, 1, 'SAME')[0]
+    outs = {}
+    for policy in (0, 2):
+        was, halo0 = lib.call('tg_conv3x3_policy', policy), lib.call('tg_conv3x3_launches')
+        y1 = torch.full((n, hw, hw, cout), 7.0, device='cuda')
+        lib.call('tg_igemm_' + prec, d_act, lib.ptr(x), lib.ptr(w_oti), lib.ptr(bias), lib.ptr(y1), st())
+        y2, s2 = torch.full((n, hw, hw, cout), 7.0, device='cuda'), torch.zeros(2 * len(segs) * cout, device='cuda')
+        lib.call('tg_igemm_colsum_' + prec, d_lin, lib.ptr(x), lib.ptr(w_oti), lib.ptr(y2), sa, len(segs), lib.ptr(s2), 0, st())
+        g3, s3 = torch.full((n, hw, hw, cin), 7.0, device='cuda'), torch.zeros(2 * len(segs) * cin, device='cuda')
+        lib.call('tg_igemm_actsum_' + prec, d_bwd, lib.ptr(dy), lib.ptr(w_hwio), lib.ptr(x), lib.ACT['lrelu'], 0.2, lib.ptr(g3), sa, len(segs),
+                 lib.ptr(s3), 0, st())
+        lib.call('tg_conv3x3_policy', was)
+        assert lib.call('tg_conv3x3_launches') - halo0 == (3 if policy == 0 else 0)
+        outs[policy] = [t.cpu().numpy() for t in (y1, y2, s2, g3, s3)]
+    scale, scale_g = float(x.abs().max()) * 0.5 * 9 * cin, float(dy.abs().max()) * 0.5 * 9 * cout
+    for i, sc in ((0, scale), (1, scale), (3, scale_g)):
+        assert np.abs(outs[0][i] - outs[2][i]).max() <= 3e-5 * sc, i
+    sums = lambda a: np.frombuffer(a.tobytes(), np.float64)
+    np.testing.assert_allclose(sums(outs[0][2]), sums(outs[2][2]), rtol=1e-5, atol=1e-6 * scale * max(segs) * hw * hw)
+    np.testing.assert_allclose(sums(outs[0][4]), sums(outs[2][4]), rtol=1e-5, atol=1e-6 * scale_g * max(segs) * hw * hw)
