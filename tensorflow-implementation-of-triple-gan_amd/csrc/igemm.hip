@@ -45,6 +45,15 @@ __device__ __forceinline__ bf16x8 cvt8(f32x4 lo, f32x4 hi) {
   return r;
 }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x2 pack4_bf16(u32x4 v) {          // 4 fp32 -> 4 bf16 (RNE), channel order kept
+  return __builtin_bit_cast(u32x2, __builtin_convertvector(__builtin_bit_cast(f32x4, v), bf16x4_t));
+}
+
 constexpr int BK = 32;    // reduction depth per LDS tile
 constexpr int LDT = 36;   // padded LDS row stride (floats)
 
@@ -93,7 +102,6 @@ struct IgemmParams {
   int nseg, seg_rows[8];
 };
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   switch (act) {
@@ -484,6 +492,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
   constexpr int AR = CT / 32, BR = NT / 32;            // 16-B loads per thread per tile
   constexpr int ASEG = CT / 4, BSEG = NT / 4;          // 16-B segments per pixel row
   constexpr int TILE = BK * (CT + NT);
+  // bf16 operands, 128 x 128 tiles (the classifier's large layers): both LDS images hold bf16 in 256-byte pixel rows — converted once on
+  // the global -> LDS path — and the pixel-major (K-major) fragments are read with the transposing ds_read_b64_tr_b16: two reads per
+  // 32x32x16 fragment instead of eight ds_read_b32 + four conversions, half the LDS bytes.  16-byte chunk index XOR-swizzled by
+  // ((row & 3) << 2) | ((row >> 2) & 3): row stores and transposed reads are then both conflict-free.  Other tile shapes keep fp32 images.
+  constexpr bool TR = BF16 && CT == 128 && NT == 128;
   constexpr int RED = (WAVES_K > 1) ? (WAVES_K - 1) * 64 * 16 * MI * NI * WAVES_C * WAVES_N : 0;
   constexpr int SM = (2 * TILE > RED ? 2 * TILE : RED) + 8 * BK;
   __shared__ __attribute__((aligned(16))) float smem[SM];
@@ -545,13 +558,29 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
 #pragma unroll
     for (int j = 0; j < BR; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_do, (uint32_t)ti[BK + brow + j * (256 / BSEG)] + b_add, 0, 0);
   };
+  auto tr_off = [](int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); };
   auto sstore = [&](int buf) {
     float* a = smem + buf * TILE;
     float* bb = a + BK * CT;
+    if constexpr (TR) {
+      unsigned char* a8 = reinterpret_cast<unsigned char*>(a);
+      unsigned char* b8 = a8 + BK * 256;
 #pragma unroll
-    for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4*>(a + (arow + j * (256 / ASEG)) * CT + aseg * 4) = ra[j];
+      for (int j = 0; j < AR; ++j) {
+        const int row = arow + j * (256 / ASEG);
+        *reinterpret_cast<u32x2*>(a8 + tr_off(row, aseg >> 1) + 8 * (aseg & 1)) = pack4_bf16(ra[j]);
+      }
 #pragma unroll
-    for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x4*>(bb + (brow + j * (256 / BSEG)) * NT + bseg * 4) = rb[j];
+      for (int j = 0; j < BR; ++j) {
+        const int row = brow + j * (256 / BSEG);
+        *reinterpret_cast<u32x2*>(b8 + tr_off(row, bseg >> 1) + 8 * (bseg & 1)) = pack4_bf16(rb[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4*>(a + (arow + j * (256 / ASEG)) * CT + aseg * 4) = ra[j];
+#pragma unroll
+      for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x4*>(bb + (brow + j * (256 / BSEG)) * NT + bseg * 4) = rb[j];
+    }
   };
 
   const int wk = wave % WAVES_K;
@@ -584,7 +613,39 @@ __global__ void __launch_bounds__(256, 2) wgrad_f32_kernel(WgradParams p) {
     if (tid < BK && it + 3 < nk) fill_tbl(it + 3);
     const float* A = smem + buf * TILE + (16 * half) * CT + wc0 + col;
     const float* B = smem + buf * TILE + BK * CT + (16 * half) * NT + wn0 + col;
-    if constexpr (BF16) {
+    if constexpr (TR) {
+      // fragment of lane (column i = lane & 31, k-group h = lane >> 5): pixels 16G + 8h + {0..7} of channel (tile column) i.  A transposed
+      // read serves 16 lanes with a block of 4 pixel rows x 16 channels: lane 4q + p of the group addresses row q, channels 4p..4p+3 and
+      // receives the four rows of channel (lane & 15); two blocks (rows +0..3, +4..7) make the eight k values.
+      const unsigned char* a8 = reinterpret_cast<const unsigned char*>(smem + buf * TILE);
+      const unsigned char* b8 = a8 + BK * 256;
+      const int q = (lane >> 2) & 3, cq = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);        // row within the block, first channel this lane addresses
+#pragma unroll
+      for (int G = wk; G < BK / 16; G += WAVES_K) {
+        bf16x8 a[MI], bv[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int cs = wc0 + mi * 32 + cq;
+          const int r0 = 16 * G + 8 * half + q;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a8 + tr_off(r0, cs >> 3) + 8 * ((cs >> 2) & 1)));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a8 + tr_off(r0 + 4, cs >> 3) + 8 * ((cs >> 2) & 1)));
+          a[mi] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int cs = wn0 + ni * 32 + cq;
+          const int r0 = 16 * G + 8 * half + q;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b8 + tr_off(r0, cs >> 3) + 8 * ((cs >> 2) & 1)));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b8 + tr_off(r0 + 4, cs >> 3) + 8 * ((cs >> 2) & 1)));
+          bv[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+      }
+    } else if constexpr (BF16) {
       // lane half h supplies pixels 16G + 8h + {0..7} of 16-pixel group G (eight conflict-free ds_read_b32 per fragment)
       const float* Ab = smem + buf * TILE + (8 * half) * CT + wc0 + col;
       const float* Bb = smem + buf * TILE + BK * CT + (8 * half) * NT + wn0 + col;
