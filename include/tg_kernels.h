@@ -162,6 +162,7 @@ int tg_dense_splitk_desc(int m, int k_dim, int n_out, int splits, tg_igemm_desc*
 /* pixel splits tg_wgrad_f32 should be given for descriptor d (fills one round of the resident workgroups; >= 1, < 0 on error) and the
  * bytes of its slab for n_split; bytes of one prepared filter layout [n_taps][c_in_pad][c_out_pad]. */
 int tg_wgrad_splits(const tg_igemm_desc* d);
+int tg_wgrad_splits_bf16(const tg_igemm_desc* d);    /* the same for tg_wgrad_bf16 (its 3x3 / stride-1 layers run on a kernel of their own: csrc/wgrad3x3.hip) */
 int64_t tg_wgrad_workspace_bytes(const tg_igemm_desc* d, int n_split);
 int64_t tg_filter_workspace_bytes(int n_taps, int c_in_pad, int c_out_pad);
 /* the workgroup tile (rows x columns) the launcher picks for these sub-problems (nseg > 0: the tg_igemm_colsum_* constraint that a

@@ -1209,6 +1209,10 @@ int pick_bm(const tg_igemm_desc* d) {
 
 namespace tg {
 
+int halo_policy() { return g_policy; }
+int halo_compute_units() { return compute_units(); }
+void halo_count_launch() { ++g_launches; }
+
 // the layer has the kernel's shape (independent of how many images the launch holds)
 static bool conv3x3_fits(const tg_igemm_desc* d, int n_desc, const int32_t* seg_rows, int nseg, bool bf16) {
   if ((bf16 ? g_disabled : g_disabled_f32) || g_policy == 2) return false;

@@ -11,6 +11,7 @@
 
 #include "tg_common.h"
 #include "tg_geom.h"
+#include "tg_conv3x3_bf16.h"
 
 namespace {
 
@@ -262,6 +263,14 @@ int tg_wgrad_splits(const tg_igemm_desc* d) {
   int64_t ns = 512 / tiles;
   if (ns > m / 128) ns = m / 128;
   return (int)(ns < 1 ? 1 : ns);
+}
+
+int tg_wgrad_splits_bf16(const tg_igemm_desc* d) {
+  if (!d || d->ld_in <= 0 || d->c_out <= 0 || d->n_taps <= 0) { tg::set_error("wgrad_splits_bf16: bad descriptor"); return TG_ERR_INVALID; }
+  // the classifier's 3x3 layers run on wgrad3x3.hip with bf16 operands: one workgroup (32 input channels x 128 output channels x the nine taps)
+  // per compute unit; everything else as tg_wgrad_splits
+  const int ns = tg::wgrad3x3_splits(d, true, tg::halo_policy(), tg::halo_compute_units());
+  return ns > 0 ? ns : tg_wgrad_splits(d);
 }
 
 int64_t tg_wgrad_workspace_bytes(const tg_igemm_desc* d, int n_split) {

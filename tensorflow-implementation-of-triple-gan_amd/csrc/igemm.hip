@@ -961,6 +961,10 @@ static int wgrad_impl(const tg_igemm_desc* d, const float* in, const float* dout
            bf16 ? " bf16" : "");
   tg::ProfScope prof(tg::PC_WGRAD, flops, bytes, tg::as_stream(stream), desc);
   hipStream_t s = tg::as_stream(stream);
+  if (tg::wgrad3x3_applicable(d, n_split, bf16, tg::halo_policy(), tg::halo_compute_units())) {      // the classifier's 3x3 layers: wgrad3x3.hip
+    tg::halo_count_launch();
+    return tg::wgrad3x3_launch(d, in, dout, slab, n_split, p.in_bytes, p.dout_bytes, s, bf16);
+  }
   // channel tiles: tg::wgrad_tile (geom.cpp; tg_wgrad_splits sizes the pixel split with the same rule)
   const int ct = tg::wgrad_tile(d->ld_in), nt = tg::wgrad_tile(d->c_out);
   if (ct == 128 && nt == 128) launch_wgrad<128, 128, 2, 2, 1>(p, s, bf16);

@@ -15,4 +15,15 @@ int conv3x3_bf16_launch(const tg_igemm_desc* d, const float* in, const float* w,
                         const int32_t* seg_rows, int nseg, const float* ymul, int ymul_act, float ymul_alpha, uint32_t in_bytes, uint32_t w_bytes,
                         uint32_t out_bytes, hipStream_t s, bool bf16);
 
+// shared by the halo kernels (conv3x3_bf16.hip owns the state): tg_conv3x3_policy's value, the device's CU count, the launch counter
+int halo_policy();
+int halo_compute_units();
+void halo_count_launch();
+
+// wgrad3x3.hip: the filter gradient of the same layers with the activation tile read once for the nine taps
+bool wgrad3x3_applicable(const tg_igemm_desc* d, int n_split, bool bf16, int policy, int compute_units);
+int wgrad3x3_splits(const tg_igemm_desc* d, bool bf16, int policy, int compute_units);
+int wgrad3x3_launch(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, uint32_t in_bytes, uint32_t dout_bytes,
+                    hipStream_t s, bool bf16);
+
 }  // namespace tg

@@ -88,9 +88,9 @@ def dense_fwd_splitk(m, k_dim, n_out, splits):
     return [arr[i] for i in range(splits)]
 
 
-def wgrad_splits(desc):
-    """pixel splits tg_wgrad_f32 should be given for `desc`."""
-    return lib.call('tg_wgrad_splits', C.byref(desc))
+def wgrad_splits(desc, bf16=False):
+    """pixel splits tg_wgrad_f32 (bf16: tg_wgrad_bf16) should be given for `desc`."""
+    return lib.call('tg_wgrad_splits_bf16' if bf16 else 'tg_wgrad_splits', C.byref(desc))
 
 
 def wgrad_slab_floats(desc, n_split):

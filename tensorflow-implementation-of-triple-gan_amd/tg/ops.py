@@ -71,7 +71,7 @@ def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst, wn=None, defer=Tru
     The tail (slab reduction [+ weight-norm gradient]) is DEFERRED to Context.flush_tails (end of the backward pass / bucket
     boundary), where the tails of all layers go out as three launches; the 512-split first convolution keeps its own reduce."""
     cx = ctx()
-    ns = geom.wgrad_splits(desc)                      # pixel split and slab size: the library's rule (tg_wgrad_splits)
+    ns = geom.wgrad_splits(desc, cx.mfma_dtype == 'bf16')      # pixel split and slab size: the library's rule (tg_wgrad_splits[_bf16])
     slab = cx.scratch('slab', geom.wgrad_slab_floats(desc, ns))
     _call('tg_wgrad_f32', desc, _p(in_act_t), _p(dout_t), _p(slab), ns, cx.stream)
     deferred = defer and (cx.tape is not None or cx._phase_depth > 0)

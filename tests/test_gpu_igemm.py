@@ -123,7 +123,10 @@ def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad, prec):
     nsplit = 3
     slab = torch.full((nsplit, k * k, ci_p, co_p), 7.0, device='cuda')
     dw_desc = geom.conv_wgrad(n, h, w, ci_p, co_p, k, s, pad)
+    halo0 = lib.call('tg_conv3x3_launches')
     lib.call("tg_wgrad_" + prec, dw_desc, lib.ptr(xd), lib.ptr(dyd), lib.ptr(slab), nsplit, lib.cur_stream())
+    # csrc/wgrad3x3.hip (activation tile read once for the nine taps): 3x3 / stride 1 / SAME, width 16 / 32 / 64, 128 | output channels
+    assert lib.call('tg_conv3x3_launches') - halo0 == int(k == 3 and s == 1 and pad == 'SAME' and w in (16, 32, 64) and co_p % 128 == 0)
     dw = slab.cpu().numpy().sum(0)
     close(dw[:, :cin, :cout].reshape(wt.shape), dw_ref, np.abs(x).max() * np.abs(dy).max() * n * ho * wo)
     assert (dw[:, cin:, :] == 0).all() and (dw[:, :, cout:] == 0).all()

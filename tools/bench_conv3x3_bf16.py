@@ -43,11 +43,16 @@ for name, hw, ci, co in LAYERS:
     gf = 2.0 * N * hw * hw * 9 * ci * co / 1e9
     out = dict(layer=name, gflop=round(gf, 1))
     only = os.environ.get('TG_BENCH_ONLY')
-    for tag, fn in (('bf16', lambda: lib.call('tg_igemm_bf16', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st)),
+    dw = geom.conv_wgrad(N, hw, hw, ci, co, 3, 1, 'SAME')
+    ns, ns16 = geom.wgrad_splits(dw), geom.wgrad_splits(dw, True)
+    slab = torch.empty(max(ns, ns16) * 9 * ci * co, device='cuda')
+    for tag, fn in (('wgrad_bf16', lambda: lib.call('tg_wgrad_bf16', dw, lib.ptr(x), lib.ptr(y), lib.ptr(slab), ns16, st)),
+                    ('wgrad_f32', lambda: lib.call('tg_wgrad_f32', dw, lib.ptr(x), lib.ptr(y), lib.ptr(slab), ns, st)),
+                    ('bf16', lambda: lib.call('tg_igemm_bf16', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st)),
                     ('bf16_colsum', lambda: lib.call('tg_igemm_colsum_bf16', dc, lib.ptr(x), lib.ptr(w), lib.ptr(y), seg, 1, lib.ptr(sums), 0, st)),
                     ('f32', lambda: lib.call('tg_igemm_f32', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st))):
         if only and tag != only:
             continue
         ms = timeit(fn)
-        out[tag] = dict(ms=round(ms, 4), tflops=round(gf / ms, 1), frac_of_bf16_peak=round(gf / ms / PEAK_BF16, 4) if tag != 'f32' else None)
+        out[tag] = dict(ms=round(ms, 4), tflops=round(gf / ms, 1), frac_of_bf16_peak=round(gf / ms / PEAK_BF16, 4) if 'f32' not in tag else None)
     print(json.dumps(out), flush=True)
