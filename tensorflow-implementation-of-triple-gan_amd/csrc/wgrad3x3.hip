@@ -229,7 +229,8 @@ void launch(const WParams& p, bool bf16, hipStream_t s) {
   else hipLaunchKernelGGL((wgrad3x3_kernel<W, false>), grid, dim3(512), 0, s, p);
 }
 
-const bool g_off = getenv("TG_NO_WGRAD3X3") != nullptr;          // A/B switch, read once at library load
+const bool g_off = getenv("TG_NO_WGRAD3X3") != nullptr;          // A/B switches, read once at library load
+const bool g_f32 = getenv("TG_WGRAD3X3_F32") != nullptr;         // fp32 launches too under the default policy
 
 }  // namespace
 
@@ -256,7 +257,7 @@ bool wgrad3x3_applicable(const tg_igemm_desc* d, int n_split, bool bf16, int pol
   if (policy == 0) {
     // exact fp32: measured 106-114 TFLOP/s against the generic kernel's 121-129 on the classifier's layers (the fp32 MFMA is bound by the
     // matrix pipe either way, and 144 accumulator registers leave one workgroup per CU) -> tests and A/B runs only (policy 1)
-    if (!bf16) return false;
+    if (!bf16 && !g_f32) return false;
     const long wgs = (long)(d->ld_in / CC) * (d->c_out / NT) * n_split;
     if (wgs * 10 < (long)compute_units * 6 || wgs > 2L * compute_units) return false;
   }
