@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 SMALL = dict(B_G=16, L_C=8, U_C=8, L_D=4, U_D=12)
 
 
-def run(use_graph, steps=4, sizes=SMALL):
-    tr = G.fresh_trainer(G.make_config(sizes, USE_HIP_GRAPH=use_graph, SEED=3))
+def run(use_graph, steps=4, sizes=SMALL, **over):
+    tr = G.fresh_trainer(G.make_config(sizes, USE_HIP_GRAPH=use_graph, SEED=3, **over))
     tr.set_hyper(lambda_1=0.3, lambda_2=0.5)
     full = dict(S.SIZES, **sizes)
     losses = []
@@ -51,3 +51,19 @@ def test_graph_replay_equals_eager_at_the_benchmark_sizes():
     for net in p_e:
         np.testing.assert_array_equal(p_e[net], p_g[net])
         np.testing.assert_array_equal(p_g[net], p_h[net])
+
+
+def test_graph_replay_equals_eager_with_bf16_operands_at_the_benchmark_sizes():
+    """configs[3]'s operand type on the bench shapes: the launches that exist only there — the pipelined 3x3 kernel with its per-launch
+    filter pack into the scratch ring and LDS-DMA fetches, the split 130-image launches, wgrad3x3 with tg_wgrad_splits_bf16 — captured
+    and replayed: bit-identical to the eager run (the ring slots baked into the graph are the ones the eager order would use)."""
+    from tg import lib
+    sizes = dict(S.SIZES)
+    halo0 = lib.call('tg_conv3x3_launches')
+    l_e, p_e, _ = run(False, 3, sizes, MFMA_DTYPE='bf16')
+    assert lib.call('tg_conv3x3_launches') - halo0 >= 3 * 20          # the halo kernels really ran (27+ launches per iteration)
+    l_g, p_g, g_g = run(True, 3, sizes, MFMA_DTYPE='bf16')
+    assert all(h is not None for h in g_g['full'])
+    assert l_e == l_g and all(np.isfinite(v) for l in l_g for v in l)
+    for net in p_e:
+        np.testing.assert_array_equal(p_e[net], p_g[net])
