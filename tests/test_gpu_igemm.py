@@ -71,6 +71,7 @@ CONV_CASES = [  # n,h,w,cin,cout,k,stride,pad
     (3, 32, 32, 128, 128, 3, 1, 'SAME'),
     (2, 16, 16, 128, 256, 3, 1, 'SAME'),
     (1, 64, 64, 64, 128, 3, 1, 'SAME'),
+    (2, 16, 16, 64, 120, 3, 1, 'SAME'),      # 120 logical output channels in 128 padded ones on the halo kernels (zero filter rows / bias beyond 120; pads come out exactly 0)
 ]
 
 
