@@ -90,67 +90,69 @@ __global__ void __launch_bounds__(512, 2) wgrad3x3_kernel(WParams p) {
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
     const int lt = tid - 256;
-    uint32_t x_voff[X_IT], d_voff[D_IT];
-    int x_lds[X_IT], d_lds[D_IT];
-#pragma unroll
-    for (int i = 0; i < D_IT; ++i) {                              // gradient tile: pixel u / 32, 16-byte unit u % 32 of its 128 columns
-      const int u = lt + 256 * i, px = u >> 5, q = u & 31;
-      d_voff[i] = (uint32_t)(px * p.ld_out + n0 + 4 * q) * 4u;
-      d_lds[i] = BF16 ? dy_off(px, q >> 1) + 8 * (q & 1) : px * DROW + q * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < X_IT; ++i) {                              // halo: pixel u / 8, unit u % 8 of its 32 channels
-      const int u = lt + 256 * i, hp = u >> 3, q = u & 7;
-      x_lds[i] = hp < HP ? hp * XROW + q * (BF16 ? 8 : 16) : -1;
-    }
-    auto set_tile = [&](int t) {
+    // Two tiles of loads are in flight (register sets A and B, the loop is unrolled by two so that both are statically named): the loads
+    // of tile t + 2 are issued at the top of iteration t, before the set holding tile t + 1 is converted and written to the other LDS
+    // stage, and stay in flight across the barrier (barrier_keep<N>) — a load has a whole iteration to land.  With one set, issued and
+    // consumed in the same iteration, the loaders spent an HBM latency per 2 304-cycle step (matrix pipe busy 27-35 %, PMC).
+    // Addressing is kept out of the registers: unit u = lt + 256 i of a tile is pixel (lt >> 5) + 8 i of the gradient tile (its 16-byte
+    // unit lt & 31) — one per-lane offset + a scalar per i — and halo pixel (lt >> 3) + 32 i (unit lt & 7).
+    constexpr int NLD = X_IT + D_IT;
+    const int dq = lt & 31, dpx = lt >> 5, xq = lt & 7, xhp = lt >> 3;
+    const uint32_t d_voff = (uint32_t)(dpx * p.ld_out + n0 + 4 * dq) * 4u;
+    const uint32_t d_step = (uint32_t)(8 * p.ld_out * 4);
+    auto x_voff = [&](int t, int i) -> uint32_t {                  // halo pixel xhp + 32 i of tile t: global byte offset, OOB outside the image
       const int img = t / tiles_per_img, row0 = (t - img * tiles_per_img) * R;
-      int ltv = lt;
-      asm volatile("" : "+v"(ltv));                               // per-tile values: keeps the halo coordinates out of the registers between tiles
-#pragma unroll
-      for (int i = 0; i < X_IT; ++i) {
-        const int u = ltv + 256 * i, hp = u >> 3, q = u & 7;
-        const int hy = hp / HW_, hx = hp - hy * HW_;
-        const int iy = row0 + hy - 1, ix = hx - 1;
-        const bool ok = hp < HP && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)W;
-        x_voff[i] = ok ? (uint32_t)(((img * p.h + iy) * W + ix) * p.ld_in + c0 + 4 * q) * 4u : OOB;
-      }
+      const int hp = xhp + 32 * i;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int iy = row0 + hy - 1, ix = hx - 1;
+      const bool ok = hp < HP && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)W;
+      return ok ? (uint32_t)(((img * p.h + iy) * W + ix) * p.ld_in + c0 + 4 * xq) * 4u : OOB;
     };
-    u32x4 rx[X_IT], rd[D_IT];
-    auto gload = [&](int t) {
-      set_tile(t);
+    struct Set { u32x4 x[X_IT], d[D_IT]; };
+    auto gload = [&](Set& r, int t) {
       const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(t * BMW * p.ld_out * 4);
 #pragma unroll
-      for (int i = 0; i < X_IT; ++i) rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_voff[i], 0, 0);
+      for (int i = 0; i < X_IT; ++i) r.x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_voff(t, i), 0, 0);
 #pragma unroll
-      for (int i = 0; i < D_IT; ++i) rd[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, d_voff[i], so, 0);
+      for (int i = 0; i < D_IT; ++i) r.d[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, d_voff, so + (uint32_t)i * d_step, 0);
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](const Set& r, int buf) {
       unsigned char* xs = smem + buf * STAGE;
       unsigned char* ds = xs + X_BYTES;
 #pragma unroll
       for (int i = 0; i < X_IT; ++i)
-        if (x_lds[i] >= 0) {
-          if constexpr (BF16) *reinterpret_cast<u32x2*>(xs + x_lds[i]) = pack4(rx[i]);
-          else *reinterpret_cast<u32x4*>(xs + x_lds[i]) = rx[i];
+        if (i + 1 < X_IT || xhp + 32 * i < HP) {
+          unsigned char* dst = xs + (xhp + 32 * i) * XROW + xq * (BF16 ? 8 : 16);
+          if constexpr (BF16) *reinterpret_cast<u32x2*>(dst) = pack4(r.x[i]);
+          else *reinterpret_cast<u32x4*>(dst) = r.x[i];
         }
 #pragma unroll
       for (int i = 0; i < D_IT; ++i) {
-        if constexpr (BF16) *reinterpret_cast<u32x2*>(ds + d_lds[i]) = pack4(rd[i]);
-        else *reinterpret_cast<u32x4*>(ds + d_lds[i]) = rd[i];
+        const int px = dpx + 8 * i;
+        if constexpr (BF16) *reinterpret_cast<u32x2*>(ds + dy_off(px, dq >> 1) + 8 * (dq & 1)) = pack4(r.d[i]);
+        else *reinterpret_cast<u32x4*>(ds + px * DROW + dq * 16) = r.d[i];
       }
     };
-    gload(t0);
-    sstore(0);
-    barrier_keep<0>();                                            // (P) the first tile is in LDS
-    int buf = 0;
-    for (int t = t0; t < t1; ++t) {
-      if (t + 1 < t1) {
-        gload(t + 1);
-        sstore(buf ^ 1);                                          // the other stage: last read one tile ago
-      }
-      barrier_keep<0>();                                          // (S) the consumers are done with tile t, tile t + 1 is in LDS
-      buf ^= 1;
+    Set A, B;
+    gload(A, t0);
+    if (t0 + 1 < t1) gload(B, t0 + 1);
+    sstore(A, 0);                                                 // waits for set A only (the compiler counts B's younger loads out)
+    if (t0 + 1 < t1) barrier_keep<NLD>();                         // (P) the first tile is in LDS; B stays in flight
+    else barrier_keep<0>();
+    for (int t = t0; t < t1; t += 2) {
+      // iteration t (consumers on stage 0): tile t + 1 is in set B, tile t + 2 goes to set A
+      const bool more2 = t + 2 < t1;
+      if (more2) gload(A, t + 2);
+      if (t + 1 < t1) sstore(B, 1);
+      if (more2) barrier_keep<NLD>();                             // (S)
+      else barrier_keep<0>();
+      if (t + 1 >= t1) break;
+      // iteration t + 1 (consumers on stage 1): tile t + 2 is in set A, tile t + 3 goes to set B
+      const bool more3 = t + 3 < t1;
+      if (more3) gload(B, t + 3);
+      if (more2) sstore(A, 0);
+      if (more3) barrier_keep<NLD>();                             // (S)
+      else barrier_keep<0>();
     }
   } else {
     // ================================================= consumers ===================================================================

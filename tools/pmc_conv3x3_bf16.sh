@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes on the halo-tiled 3x3 micro-benchmark (tools/bench_conv3x3_bf16.py; counters in their own runs, no trace domains, and a
-# kernel trace for the durations).  Usage: tools/pmc_conv3x3_bf16.sh [bf16|f32]; summary: tools/pmc_conv3x3_summarize.py <dir>.
+# kernel trace for the durations).  Usage: tools/pmc_conv3x3_bf16.sh [bf16|f32|bf16_colsum|wgrad_bf16|wgrad_f32]; summary: tools/pmc_conv3x3_summarize.py <dir>.
 P=${1:-bf16}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc_c3_$P

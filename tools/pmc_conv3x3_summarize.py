@@ -11,7 +11,7 @@ def latest(sub, pat):
 
 
 def key_of(r):
-    m = re.search(r'(conv3x3_\w+_kernel<[^>]*>)', r['Kernel_Name'])
+    m = re.search(r'((?:conv3x3_\w+|wgrad3x3)_kernel<[^>]*>)', r['Kernel_Name'])
     if not m:
         return None
     gx = int(r['Grid_Size_X'] if 'Grid_Size_X' in r else r['Grid_Size'])
