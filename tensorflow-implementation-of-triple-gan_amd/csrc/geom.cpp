@@ -255,7 +255,9 @@ int tg_dense_splitk_desc(int m, int k_dim, int n_out, int splits, tg_igemm_desc*
 
 int tg_wgrad_splits(const tg_igemm_desc* d) {
   if (!d || d->ld_in <= 0 || d->c_out <= 0 || d->n_taps <= 0) { tg::set_error("wgrad_splits: bad descriptor"); return TG_ERR_INVALID; }
-  // fill ONE round of the 512 resident workgroups (256 CUs x 2) as fully as possible — 576 blocks take two rounds and run at 56 % —
+  // the classifier's 3x3 / stride-1 layers run on wgrad3x3.hip: one workgroup (32 input channels x 128 output channels x nine taps) per CU
+  if (const int ns3 = tg::wgrad3x3_splits(d, false, tg::halo_policy(), tg::halo_compute_units())) return ns3;
+  // generic kernel: fill ONE round of the 512 resident workgroups (256 CUs x 2) as fully as possible — 576 blocks take two rounds and run at 56 % —
   // with at least 128 pixels (4 K-tiles) per split
   const int ct = tg::wgrad_tile(d->ld_in), nt = tg::wgrad_tile(d->c_out);
   const int64_t tiles = (int64_t)d->n_taps * ((d->ld_in + ct - 1) / ct) * ((d->c_out + nt - 1) / nt);
@@ -269,7 +271,7 @@ int tg_wgrad_splits_bf16(const tg_igemm_desc* d) {
   if (!d || d->ld_in <= 0 || d->c_out <= 0 || d->n_taps <= 0) { tg::set_error("wgrad_splits_bf16: bad descriptor"); return TG_ERR_INVALID; }
   // the classifier's 3x3 layers run on wgrad3x3.hip with bf16 operands: one workgroup (32 input channels x 128 output channels x the nine taps)
   // per compute unit; everything else as tg_wgrad_splits
-  const int ns = tg::wgrad3x3_splits(d, true, tg::halo_policy(), tg::halo_compute_units());
+  const int ns = tg::wgrad3x3_splits(d, true, tg::halo_policy(), tg::halo_compute_units());     // 128-pixel tiles (fp32: 64)
   return ns > 0 ? ns : tg_wgrad_splits(d);
 }
 

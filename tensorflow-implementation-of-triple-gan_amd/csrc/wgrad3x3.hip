@@ -232,14 +232,15 @@ void launch(const WParams& p, bool bf16, hipStream_t s) {
 }
 
 const bool g_off = getenv("TG_NO_WGRAD3X3") != nullptr;          // A/B switches, read once at library load
-const bool g_f32 = getenv("TG_WGRAD3X3_F32") != nullptr;         // fp32 launches too under the default policy
+const bool g_no_f32 = getenv("TG_NO_WGRAD3X3_F32") != nullptr;   // fp32 launches stay on the generic kernel
 
 }  // namespace
 
 namespace tg {
 
 // 3x3 window (each tap once), stride 1, output grid = input grid, width 16 / 32 / 64, whole tiles of image rows, 32 | ld_in, 128 | c_out;
-// with the default policy (tg_conv3x3_policy 0) only when the launch puts a workgroup on at least 60 % of the compute units
+// with the default policy (tg_conv3x3_policy 0) only when the launch puts a workgroup on 60 % ... 200 % of the compute units (a caller
+// that passes the split of tg_wgrad_splits[_bf16] does)
 bool wgrad3x3_applicable(const tg_igemm_desc* d, int n_split, bool bf16, int policy, int compute_units) {
   if (g_off || policy == 2) return false;
   if (d->n_taps != 9 || d->n_group != 0) return false;
@@ -257,16 +258,16 @@ bool wgrad3x3_applicable(const tg_igemm_desc* d, int n_split, bool bf16, int pol
     seen[k] = true;
   }
   if (policy == 0) {
-    // exact fp32: measured 106-114 TFLOP/s against the generic kernel's 121-129 on the classifier's layers (the fp32 MFMA is bound by the
-    // matrix pipe either way, and 144 accumulator registers leave one workgroup per CU) -> tests and A/B runs only (policy 1)
-    if (!bf16 && !g_f32) return false;
+    // exact fp32: 130 / 128 / 139 TFLOP/s on conv1_2 / conv2_1 / conv2_2 with one workgroup on every CU (the split rule below) against
+    // the generic kernel's 125 / 118 / 129; TG_NO_WGRAD3X3_F32 switches it off for A/B runs
+    if (!bf16 && g_no_f32) return false;
     const long wgs = (long)(d->ld_in / CC) * (d->c_out / NT) * n_split;
     if (wgs * 10 < (long)compute_units * 6 || wgs > 2L * compute_units) return false;
   }
   return true;
 }
 
-// pixel splits that put one workgroup of this kernel on every compute unit (tg_wgrad_splits_bf16); 0: the layer is not this kernel's
+// pixel splits that put one workgroup of this kernel on every compute unit (tg_wgrad_splits / tg_wgrad_splits_bf16); 0: the layer is not this kernel's
 int wgrad3x3_splits(const tg_igemm_desc* d, bool bf16, int policy, int compute_units) {
   const long per_split = (long)(d->ld_in / CC) * (d->c_out / NT);
   if (per_split < 1) return 0;

@@ -86,12 +86,15 @@ def test_tile_and_colsum_rules_live_in_the_library():
 
 
 def test_wgrad_split_rule_for_bf16_operands():
-    """tg_wgrad_splits_bf16: the classifier's 3x3 / stride-1 layers run on csrc/wgrad3x3.hip with bf16 operands — one workgroup (32 input channels x
+    """tg_wgrad_splits / tg_wgrad_splits_bf16: the classifier's 3x3 / stride-1 layers run on csrc/wgrad3x3.hip — one workgroup (32 input channels x
     128 output channels x nine taps) per compute unit, so splits = CUs / ((ld_in / 32) * (c_out / 128)) (256 CUs assumed without a device); every
     other geometry keeps tg_wgrad_splits' rule."""
     from tg import geom
     for n, hw, ci, co, want in ((250, 32, 128, 128, 64), (250, 16, 128, 256, 32), (250, 16, 256, 256, 16)):
         assert geom.wgrad_splits(geom.conv_wgrad(n, hw, hw, ci, co, 3, 1, 'SAME'), True) == want
+        assert geom.wgrad_splits(geom.conv_wgrad(n, hw, hw, ci, co, 3, 1, 'SAME'), False) == want      # the fp32 form: same workgroup shape
+    for bf16 in (True, False):                                       # 3 images: too few workgroups for that kernel -> the generic rule (>= 128 pixels per split)
+        assert geom.wgrad_splits(geom.conv_wgrad(3, 16, 16, 128, 128, 3, 1, 'SAME'), bf16) == 6
     for n, hw, ci, co, k, s in ((250, 8, 256, 512, 3, 1), (100, 32, 32, 64, 3, 2), (250, 6, 512, 256, 1, 1)):      # width 8 / stride 2 / 1x1: generic rule
         d = geom.conv_wgrad(n, hw, hw, ci, co, k, s, 'SAME')
         assert geom.wgrad_splits(d, True) == geom.wgrad_splits(d)

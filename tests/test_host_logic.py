@@ -94,10 +94,14 @@ def test_same_padding_matches_tf_rule():
 
 def test_wgrad_splits_fill_one_round():
     d = geom.conv_wgrad(250, 32, 32, 128, 128, 3, 1, 'SAME')
-    assert geom.wgrad_splits(d) == 56                                # 9 tiles * 56 = 504 <= 512 resident workgroups
-    assert geom.wgrad_slab_floats(d, 56) == 56 * 9 * 128 * 128
+    assert geom.wgrad_splits(d) == 64                                # csrc/wgrad3x3.hip: 4 channel chunks x 64 splits = one workgroup per CU (256 without a device)
+    assert geom.wgrad_slab_floats(d, 64) == 64 * 9 * 128 * 128
     d = geom.conv_wgrad(250, 16, 16, 256, 256, 3, 1, 'SAME')
-    assert geom.wgrad_splits(d) == 14
+    assert geom.wgrad_splits(d) == 16                                # 8 chunks x 2 column tiles x 16
+    d = geom.conv_wgrad(250, 8, 8, 256, 512, 3, 1, 'VALID')         # 8-wide images: the generic kernel, 9 taps x 2 x 4 tiles
+    assert geom.wgrad_splits(d) == 7                                 # 72 * 7 = 504 <= 512 resident workgroups
+    d = geom.conv_wgrad(100, 32, 32, 32, 64, 3, 2, 'SAME')
+    assert geom.wgrad_splits(d) == 56                                # stride 2: generic, 9 tiles * 56 = 504
     d = geom.dense_fwd(100, 128, 8192)
     assert geom.wgrad_splits(d) == 1                                 # never an empty split
 
