@@ -66,10 +66,10 @@ if dom:
 head = entry('conv3x3_pipe_kernel<32, true, false>', 256)
 if head and dom and head['launches_profiled'] > dom['launches_profiled']:
     out["all_launches_of_that_kernel"] = dict(head, note="250-image launches and the 128-image heads of the D-update's split 130-image launches together")
-wg = entry('wgrad_f32_kernel<128, 128, 2, 2, 1, false>', 504)
+wg = entry('wgrad3x3_kernel<32, false>', 256)
 if wg:
-    wg.update(kernel="wgrad_f32_kernel<128,128,2,2,1>, 504 workgroups: filter gradient of conv1_2 / conv1_3 (9 taps x 56 pixel splits)",
-              algorithmic_bytes=int(4 * (2 * M * C + 56 * 9 * C * C)))
+    wg.update(kernel="wgrad3x3_kernel<W=32,fp32>, 256 workgroups (4 channel chunks x 64 pixel splits): filter gradient of conv1_2 / conv1_3, activation tile read once for the nine taps",
+              algorithmic_bytes=int(4 * (2 * M * C + 64 * 9 * C * C)))
     out["wgrad_launch"] = wg
 for nm, key, wgs in (("mobn_apply", "mobn_apply", None), ("mobn_center", "mobn_center", None)):
     best = None
