@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""bf16 MFMA conv path on the classifier's 3x3 layers (BASELINE.json configs[3]): TFLOP/s of tg_igemm_bf16 / tg_igemm_colsum_bf16 (halo-tiled
-kernel, csrc/conv3x3_bf16.hip) against the generic bf16 implicit GEMM (TG_NO_CONV3X3_BF16=1) and the fp32 kernel, on standard-normal
-operands, N = 250 images.  Prints one JSON line per layer; peak = 2 500 TFLOP/s dense bf16 (MI355X_MICROARCH.md)."""
+"""The classifier's 3x3 layers on the halo kernels (csrc/conv3x3_bf16.hip, csrc/wgrad3x3.hip), N = 250 images (TG_BENCH_N), standard-normal
+operands: TFLOP/s of tg_igemm_bf16 / tg_igemm_colsum_bf16 / tg_igemm_f32 (forward) and tg_wgrad_bf16 / tg_wgrad_f32 (filter gradient, pixel
+split from tg_wgrad_splits[_bf16]).  TG_BENCH_ONLY=<bf16|bf16_colsum|f32|wgrad_bf16|wgrad_f32> runs one of them; the generic kernels for
+comparison: TG_NO_CONV3X3_BF16=1 / TG_NO_CONV3X3_F32=1 / TG_NO_WGRAD3X3=1 (TG_CONV3X3_STAGED=1: the one-tile-per-workgroup form).  One JSON
+line per layer; bf16 fractions against 2 500 TFLOP/s dense bf16 (MI355X_MICROARCH.md)."""
 import ctypes as C
 import json
 import os
