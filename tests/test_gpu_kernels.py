@@ -471,6 +471,32 @@ def test_halo_kernel_walks_several_tiles_per_workgroup(prec, hw, cin, cout, n, s
 
 
 @pytest.mark.parametrize("prec", ['f32', 'bf16'])
+@pytest.mark.parametrize("hw,cin,cout,n", [(32, 128, 128, 40), (16, 128, 256, 40), (16, 256, 256, 250), (32, 128, 128, 130)])
+def test_filter_gradient_with_the_activation_tile_read_once_equals_the_generic_kernel(prec, hw, cin, cout, n):
+    """csrc/wgrad3x3.hip under the default routing with the library's own pixel split (tg_wgrad_splits[_bf16]: one workgroup per CU, 10 - 62
+    tiles each, two tiles of loads in flight) against the generic per-tap kernel with ITS split (tg_conv3x3_policy 2), both reduced over their
+    slabs in float64: the launches of the long-horizon run (40 images) and of the bench line (130 / 250)."""
+    from tg import geom
+    lib = _lib()
+    rng = np.random.default_rng(13)
+    x = dev(rng.standard_normal((n, hw, hw, cin)))
+    dy = dev(rng.standard_normal((n, hw, hw, cout)))
+    d = geom.conv_wgrad(n, hw, hw, cin, cout, 3, 1, 'SAME')
+    got = {}
+    for policy in (0, 2):
+        was, halo0 = lib.call('tg_conv3x3_policy', policy), lib.call('tg_conv3x3_launches')
+        ns = geom.wgrad_splits(d, prec == 'bf16')
+        slab = torch.full((ns, 9, cin, cout), 7.0, device='cuda')
+        lib.call('tg_wgrad_' + prec, d, lib.ptr(x), lib.ptr(dy), lib.ptr(slab), ns, st())
+        lib.call('tg_conv3x3_policy', was)
+        assert lib.call('tg_conv3x3_launches') - halo0 == (1 if policy == 0 else 0), (policy, ns)
+        got[policy] = (ns, slab.cpu().numpy().astype(np.float64).sum(0))
+    assert got[0][0] * (cin // 32) * (cout // 128) in (256, 2 * 256 // 2) and got[0][0] != got[2][0]
+    scale = float(x.abs().max()) * float(dy.abs().max()) * np.sqrt(n * hw * hw)          # random-sign sums grow like sqrt(pixels)
+    assert np.abs(got[0][1] - got[2][1]).max() <= (2e-2 if prec == 'bf16' else 2e-5) * scale * 4
+
+
+@pytest.mark.parametrize("prec", ['f32', 'bf16'])
 @pytest.mark.parametrize("segs", [[50, 80], [129, 1], [130]])
 def test_halo_kernel_takes_the_whole_rounds_of_a_launch_and_the_generic_kernel_the_rest(prec, segs):
     """Default routing (tg_conv3x3_policy 0): 130 images of 32x32x128 -> 128 are 520 halo tiles = 2.03 rounds of one workgroup per CU; the
