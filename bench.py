@@ -11,7 +11,8 @@ replicas (weak scaling: every replica runs the single-GPU batch; gradients are s
 
 The JSON line also carries
   roofline     — the classifier's 3x3 convolution path (87 % of the step's FLOPs; the north-star kernel path): algorithmic
-                 FLOPs of its igemm (forward + input-gradient) and wgrad launches in one iteration / their summed
+                 FLOPs of its forward / input-gradient (conv3x3_pipe_kernel, igemm_f32_kernel) and filter-gradient (wgrad3x3_kernel,
+                 wgrad_f32_kernel) launches in one iteration / their summed
                  HIP-event durations, measured in an instrumented eager pass on the launch stream right after the timed
                  region (the timed region replays hipGraphs, whose inner kernels cannot be bracketed by events);
                  peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).  The figure over ALL igemm / wgrad launches
@@ -281,7 +282,7 @@ def main():
     achieved = fl['executed_igemm'] / (ig['ms_per_iter'] * 1e-3) / 1e12
     n_conv_launches = (conv_n['igemm_f32'] + conv_n['wgrad_f32']) / args.prof_iters
     traffic, traffic_detail = measured_traffic()
-    roofline = dict(bound="mfma", kernel="classifier 3x3 conv path: conv3x3_pipe_kernel / igemm_f32_kernel (fwd + input grad) + wgrad_f32_kernel",
+    roofline = dict(bound="mfma", kernel="classifier 3x3 conv path: conv3x3_pipe_kernel / igemm_f32_kernel (fwd + input grad) + wgrad3x3_kernel / wgrad_f32_kernel (filter grad)",
                     achieved=round(conv_tf, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(conv_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                     traffic=traffic, traffic_detail=traffic_detail, launches_per_step=n_conv_launches,
                     avg_launch_ms=round((conv_ms['igemm_f32'] + conv_ms['wgrad_f32']) / max(n_conv_launches, 1), 5),
