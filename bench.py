@@ -35,6 +35,7 @@ for p in (ROOT, PKG):
 import numpy as np  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
+TRAFFIC_SOURCES = ('igemm.hip', 'conv3x3_bf16.hip', 'wgrad3x3.hip')      # the kernels the roofline object names (tools/make_traffic_json.py)
 SIZES = dict(B_G=100, L_C=50, U_C=50, L_D=20, U_D=80)
 
 
@@ -145,9 +146,9 @@ def cpu_baseline(warmup=1, timed=3):
 
 def measured_traffic():
     """HBM bytes of the dominant launch from the PMC passes stored under profiles/ (rocprofv3 cannot run inside this process).  The
-    record names the kernel sources it was collected for (sha256 of csrc/igemm.hip + csrc/conv3x3_bf16.hip): for any other source the
+    record names the kernel sources it was collected for (sha256 of the files in TRAFFIC_SOURCES): for any other source the
     figure is stale and `traffic` is null."""
-    for name in ('r02_traffic.json', 'r01_traffic.json'):
+    for name in ('r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
         tfile = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(tfile):
             continue
@@ -156,7 +157,7 @@ def measured_traffic():
         want = rec.get('kernel_sources_sha256')
         csrc = os.path.join(PKG, 'csrc')
         import hashlib
-        have = hashlib.sha256(open(os.path.join(csrc, 'igemm.hip'), 'rb').read() + open(os.path.join(csrc, 'conv3x3_bf16.hip'), 'rb').read()).hexdigest()
+        have = hashlib.sha256(b''.join(open(os.path.join(csrc, f), 'rb').read() for f in rec.get('kernel_source_files', TRAFFIC_SOURCES[:2]))).hexdigest()
         if want != have:
             return None, dict(stale='profiles/%s was collected for other kernel sources (%s...), this build has %s...: re-run '
                                     'tools/pmc_traffic.sh + tools/make_traffic_json.py' % (name, str(want)[:12], have[:12]))
@@ -164,6 +165,25 @@ def measured_traffic():
             algorithmic_bytes_per_launch=tj['algorithmic_bytes'], kernel=tj['kernel'], kernel_sources_sha256=have,
             source='profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950-corrected)' % name)
     return None, None
+
+
+def store_checksums(stores):
+    """Per network two exact integers that identify the BITS of its flat parameter buffer: the sums of the low and of the high 16-bit
+    halves of every float32 word (each < 2^40 for < 2^24 words: exact in int64 and in the float64 the exchange carries)."""
+    import torch
+    out = []
+    for name in sorted(stores):
+        bits = stores[name].p.detach().contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        out += [float((bits & 0xFFFF).sum().item()), float((bits >> 16).sum().item())]
+    return out
+
+
+def replicas_identical(stores, device):
+    """every replica must hold bit-identical weights after the timed steps (identical initial weights + identical summed gradients +
+    the same Adam arithmetic): min and max over the ranks of every checksum coincide."""
+    from tg import dist as tgdist
+    lo, hi = tgdist.minmax_over_ranks(store_checksums(stores), device)
+    return lo == hi
 
 
 def main():
@@ -174,6 +194,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying hipGraphs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--prof-iters', type=int, default=2)
+    ap.add_argument('--soak-seconds', type=float, default=8.0,
+                    help='untimed graph replays after the measurement so that a coarse GPU-utilisation sampler sees the run (0: none)')
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -203,6 +225,7 @@ def main():
         raise SystemExit("asked for %d replicas, the exchange has %d (communicator: %d)" % (args.gpus, tgdist.world_size(), tgdist.rccl_ranks()))
     tr.set_hyper(lambda_1=cfg.FAKE_G_LAMBDA, lambda_2=0.5)       # the late-training schedule: every loss term active
     cx = tr.cx
+    exchange_ok_ranks = tgdist.self_test(cx.device)            # rank-id vector through the real exchange before anything is timed
 
     # synthetic batches, resident in HBM before the timed region (per-rank seed: SURVEY §8d)
     ds = syntheticDataset(None, cfg, cfg.NUM_LABEL, 'train', seed=1234 + rank)
@@ -228,6 +251,15 @@ def main():
     tgdist.barrier()
     dt = tgdist.max_over_ranks(dt_local, cx.device)
     losses = tr.losses()
+    identical = replicas_identical(cx.stores, cx.device) if world > 1 else None
+    exposed_ms = None
+    if world > 1:                                  # how much of the bucketed exchange the backward passes do not hide (untimed extra steps)
+        n_x = min(20, max(args.steps, 1))
+        tr.measure_exposed(True)
+        for i in range(n_x):
+            step(i)
+        exposed_ms = tgdist.max_over_ranks(tr.exposed_ms() / n_x, cx.device)
+        tr.measure_exposed(False)
 
     # ---- instrumented eager pass: per-kernel-class HIP-event timing on the launch stream
     fl = algorithmic_flops()
@@ -266,6 +298,10 @@ def main():
         if conv1_1 or (taps == 9 and st == 1 and ld in (128, 256, 512) and n in (128, 256, 512) and hin in (32, 16, 8, 6)):
             conv_ms[row['class']] += float(row['ms']) / args.prof_iters
             conv_n[row['class']] += 1
+    # the dominant launch on its own: the 250-image conv1_2 / conv1_3 launch of conv3x3_pipe_kernel<32> (75.5 GFLOP each) — one row of
+    # profiles/rNN_kernel_stats.csv reproduces this figure
+    dom = [float(r['ms']) for r in csv.DictReader(open(dump))
+           if r['class'] == 'igemm_f32' and re.match(r"M=(?:%dx)?1024 N=128 K=9x128 " % (SIZES['L_C'] + 2 * SIZES['U_C'] + SIZES['B_G']), r['desc'] or '')]
     if not os.environ.get('TG_PROF_DUMP'):
         os.remove(dump)
     s_ = SIZES
@@ -282,6 +318,13 @@ def main():
     achieved = fl['executed_igemm'] / (ig['ms_per_iter'] * 1e-3) / 1e12
     n_conv_launches = (conv_n['igemm_f32'] + conv_n['wgrad_f32']) / args.prof_iters
     traffic, traffic_detail = measured_traffic()
+    dom_gflop = (s_['L_C'] + 2 * s_['U_C'] + s_['B_G']) * c3[1] / 1e9
+    dominant = None
+    if dom:
+        dom_ms = sum(dom) / len(dom)
+        dominant = dict(kernel="conv3x3_pipe_kernel<32, COLSUM, fp32> on one 250-image 32x32 128->128 launch (conv1_2 / conv1_3 forward and input gradient)",
+                        launches_sampled=len(dom), avg_launch_ms=round(dom_ms, 5), algorithmic_gflop_per_launch=round(dom_gflop, 2),
+                        achieved=round(dom_gflop / dom_ms, 2), frac=round(dom_gflop / dom_ms / PEAK_FP32_MFMA_TFLOPS, 4))
     roofline = dict(bound="mfma", kernel="classifier 3x3 conv path: conv3x3_pipe_kernel / igemm_f32_kernel (fwd + input grad) + wgrad3x3_kernel / wgrad_f32_kernel (filter grad)",
                     achieved=round(conv_tf, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(conv_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                     traffic=traffic, traffic_detail=traffic_detail, launches_per_step=n_conv_launches,
@@ -293,7 +336,14 @@ def main():
                                             launches_per_step=ig['launches_per_iter'], algorithmic_gflop_per_step=round(fl['executed_igemm'] / 1e9, 1)),
                     all_wgrad_launches=dict(achieved=round(fl['wgrad'] / (classes['wgrad_f32']['ms_per_iter'] * 1e-3) / 1e12, 2),
                                             algorithmic_gflop_per_step=round(fl['wgrad'] / 1e9, 1)),
+                    dominant_launch=dominant,
                     class_ms_per_step={k: round(v['ms_per_iter'], 3) for k, v in classes.items()})
+    if args.soak_seconds > 0:                      # untimed: keeps the GPU visibly busy for a sampler that looks every few seconds
+        t_end = time.perf_counter() + args.soak_seconds
+        while time.perf_counter() < t_end:
+            for i in range(20):
+                step(i)
+            torch.cuda.synchronize()
 
     if rank == 0:
         out = {
@@ -303,6 +353,9 @@ def main():
             "n_gpus": world,
             "rccl_ranks": tgdist.rccl_ranks(),
             "dist_backend": tgdist.backend_name(),
+            "exchange_self_test_ranks": exchange_ok_ranks,
+            "replicas_identical": identical,
+            "exchange_exposed_ms": None if exposed_ms is None else round(exposed_ms, 4),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -315,7 +368,8 @@ def main():
                                    "Good_GAN_cifar10 D+G+C step", "global_batch": SIZES['B_G'] * world, "parallelism": "dp%d" % world,
                        "hip_graph": bool(cfg.USE_HIP_GRAPH), "algorithmic_gflop_per_step": round(fl['total'] / 1e9, 1),
                        "executed_gflop_per_step": round(fl['executed_total'] / 1e9, 1),
-                       "step_tflops": round(fl['total'] / (dt / args.steps) / 1e12, 2), "losses_d_g_c": [round(v, 4) for v in losses]},
+                       "step_tflops": round(fl['executed_total'] / (dt / args.steps) / 1e12, 2),
+                       "step_tflops_algorithmic": round(fl['total'] / (dt / args.steps) / 1e12, 2), "losses_d_g_c": [round(v, 4) for v in losses]},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -290,6 +290,12 @@ int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nse
 int tg_bn_train_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int c, const int32_t* seg_rows, int nseg, const float* gamma,
                     const float* beta, float eps, float decay, float* moving_mean, float* moving_var, double* sums, int sums_zeroed, float* mean_inv,
                     void* stream);
+/* One more moving-statistics update from the batch sums a tg_bn_train_f32 launch left in `sums` (same seg_rows / nseg / c / decay; the
+ * buffer must not have been cleared since): what TensorFlow does when a later sess.run re-executes the same training-mode batch norm on
+ * the same feed and weights (tf.contrib.layers.batch_norm, updates_collections=None, Model/modle_base.py:229-237) while this build
+ * re-uses the kept forward pass — bit-identical to re-running tg_bn_train_f32, without touching x / y. */
+int tg_bn_moving_update_f32(const double* sums, int rows, int c, const int32_t* seg_rows, int nseg, float decay, float* moving_mean,
+                            float* moving_var, void* stream);
 /* its backward: dx = gamma*inv*(dy - mean_s(dy) - xhat*mean_s(dy*xhat)) per segment (masked by x > 0 when relu_input: the gradient is
  * then with respect to the pre-ReLU value), dgamma = sum_s sum dy*xhat, dbeta = sum_s sum dy (both NULL: not wanted). */
 int tg_bn_train_bwd_f32(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,

@@ -16,10 +16,11 @@ from . import nets_goodgan as NG
 from . import tf_ops as T
 
 
-def forward_pass_cifar10(P, b, rnd, zca, train=True):
+def forward_pass_cifar10(P, b, rnd, zca, train=True, moving=None):
     """Model/Good_GAN_cifar10.py:204-278.  rnd keys: C_real, C_unl, C_unl_rep, C_unl_d, C_fake (classifier applications, call-site order
-    :228-240), D_real, D_fake, D_unl.  Returns ([G, D(6), C(5)], pop_mean updates) — D = [sigmoid, logits] x (real, fake, unl)."""
-    G, _ = N.generator_fwd(P, b['z_g'], b['y_g'])                                                   # :216-217
+    :228-240), D_real, D_fake, D_unl.  Returns ([G, D(6), C(5)], pop_mean updates) — D = [sigmoid, logits] x (real, fake, unl).
+    moving: dict whose generator batch-norm moving statistics this execution updates (nets_cifar10.generator_fwd)."""
+    G, _ = N.generator_fwd(P, b['z_g'], b['y_g'], moving=moving)                                    # :216-217
     pops = {}
     x_u_c_z = N.zca_apply(b['x_u_c'], *zca)                                                       # :221-225
     C_real, _, _ = N.classifier_fwd(P, N.zca_apply(b['x_l_c'], *zca), train, rnd['C_real'], pops)   # :228
@@ -89,3 +90,14 @@ def loss_gan(D, C, Y, Lambda, cifar10):
     if cifar10:
         c_loss += Lambda[1] * T.mse_mean(C_unl, C[4])[0]                                            # :118,149-152
     return float(d_loss), float(g_loss), float(c_loss)
+
+
+def training_statistics_cifar10(P, b, rnd, zca, Lambda):
+    """The end-of-epoch statistics run of Training/Train_goodGAN.py:280-285: ONE sess.run of [merged_summary_train, d_loss, g_loss, c_loss]
+    on the epoch's last feed with train_ph = True — the whole forward graph once (one draw per random op, shared by the three losses), no
+    solver.  Side effects committed to P, as the session leaves them: pop_mean of every classifier application in call-site order, the
+    generator's batch-norm moving statistics.  Returns the three losses — the numbers the reference logs (:287-288) and summarises."""
+    (G, D, C), pops = forward_pass_cifar10(P, b, rnd, zca, True, moving=P)
+    for p, v in pops.items():
+        P[p + 'meanOnlyBatchNormalization/pop_mean'] = v
+    return loss_gan(D, C, [b['y_g'], b['y_l_c']], Lambda, True)

@@ -160,8 +160,31 @@ def generator_param_shapes(z_dim=100):
     return out
 
 
-def generator_fwd(P, z, y, eps=1e-5):
-    """Good_GAN_cifar10.py:33-58 (= good_sampler :176-202). BN always in train mode."""
+BN_DECAY = 0.9      # config.BATCH_NORM_DECAY (reference config.py)
+
+
+def generator_moving_shapes():
+    """the non-trainable variables tf.contrib.layers.batch_norm creates next to beta / gamma (modle_base.py:229-237)."""
+    out = []
+    for i, cout in enumerate([8192] + [co for _, co in G_DECONVS[:2]]):
+        out += [('good_generator/gg_bn%d/moving_mean' % i, (cout,)), ('good_generator/gg_bn%d/moving_variance' % i, (cout,))]
+    return out
+
+
+def _bn_moving(P, i, cache, count, moving):
+    """updates_collections=None: every execution of a training-mode batch_norm updates its moving statistics in place — once per
+    sess.run that evaluates the generator, i.e. THREE times per iteration (Train_goodGAN.py:267,270,275).  Dead state for the losses
+    (the generator's BN is always in training mode) but checkpoint content."""
+    if moving is None:
+        return
+    km, kv = 'good_generator/gg_bn%d/moving_mean' % i, 'good_generator/gg_bn%d/moving_variance' % i
+    if km in moving:
+        moving[km], moving[kv] = T.batch_norm_moving_update(moving[km], moving[kv], cache[2], cache[3], count, BN_DECAY, fused=True)
+
+
+def generator_fwd(P, z, y, eps=1e-5, moving=None):
+    """Good_GAN_cifar10.py:33-58 (= good_sampler :176-202). BN always in train mode.  moving: the variable dict whose
+    gg_bn*/moving_mean / moving_variance entries this execution updates (None: a pure function, as the tests of the nets use it)."""
     c = {}
     zy = np.concatenate([z, y], axis=1)
     c['zy'] = zy
@@ -169,6 +192,7 @@ def generator_fwd(P, z, y, eps=1e-5):
     h = T.relu(h)
     c['r0'] = h
     h, c['bn0'] = T.batch_norm_train(h, P['good_generator/gg_bn0/gamma'], P['good_generator/gg_bn0/beta'], eps)
+    _bn_moving(P, 0, c['bn0'], h.shape[0], moving)
     h = T.conv_cond_concat(h.reshape(-1, 4, 4, 512), y)
     for i, (name, cout) in enumerate(G_DECONVS):
         p = 'good_generator/%s/%s/' % (name, name)
@@ -179,6 +203,7 @@ def generator_fwd(P, z, y, eps=1e-5):
             c['r%d' % (i + 1)] = h
             h, c['bn%d' % (i + 1)] = T.batch_norm_train(
                 h, P['good_generator/gg_bn%d/gamma' % (i + 1)], P['good_generator/gg_bn%d/beta' % (i + 1)], eps)
+            _bn_moving(P, i + 1, c['bn%d' % (i + 1)], h.size // h.shape[-1], moving)
             h = T.conv_cond_concat(h, y)
         else:
             h = np.tanh(h)

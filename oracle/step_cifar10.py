@@ -17,7 +17,7 @@ from . import nets_cifar10 as N
 
 
 def trainable(names):
-    return [n for n in names if 'pop_mean' not in n]
+    return [n for n in names if 'pop_mean' not in n and 'moving_' not in n]
 
 
 def new_state(P):
@@ -47,7 +47,7 @@ def _commit_pop(P, pop_updates):
 def d_phase(st, batch, rnd, hyper, zca):
     """sess.run([d_solver, d_loss]) — Train_goodGAN.py:267."""
     P = st['P']
-    Gimg, _ = N.generator_fwd(P, batch['z_g'], batch['y_g'])
+    Gimg, _ = N.generator_fwd(P, batch['z_g'], batch['y_g'], moving=P)
     pops = {}
     c_unl, _, _ = N.classifier_fwd(P, N.zca_apply(batch['x_u_c'], *zca), True, rnd['C_unl'], pops)
     c_unl_d, _, _ = N.classifier_fwd(P, N.zca_apply(batch['x_u_d'], *zca), True, rnd['C_unl_d'], pops)
@@ -73,7 +73,7 @@ def d_phase(st, batch, rnd, hyper, zca):
 def g_phase(st, batch, rnd, hyper):
     """sess.run([g_solver, g_loss]) — Train_goodGAN.py:270."""
     P = st['P']
-    Gimg, gc = N.generator_fwd(P, batch['z_g'], batch['y_g'])
+    Gimg, gc = N.generator_fwd(P, batch['z_g'], batch['y_g'], moving=P)
     logits, c = N.discriminator_fwd(P, Gimg, batch['y_g'], rnd['D_fake'])
     l, dl = T.bce_mean(logits, np.ones_like(logits))
     _, dimg = N.discriminator_bwd(P, c, (0.5 * dl).astype(logits.dtype), rnd['D_fake'],
@@ -86,7 +86,7 @@ def g_phase(st, batch, rnd, hyper):
 def c_phase(st, batch, rnd, hyper, zca):
     """sess.run([c_solver, c_loss]) — Train_goodGAN.py:275 (c_solver includes the EMA apply)."""
     P = st['P']
-    Gimg, _ = N.generator_fwd(P, batch['z_g'], batch['y_g'])
+    Gimg, _ = N.generator_fwd(P, batch['z_g'], batch['y_g'], moving=P)
     pops = {}
     x_u_c_z = N.zca_apply(batch['x_u_c'], *zca)
     c_real, _, cc_real = N.classifier_fwd(P, N.zca_apply(batch['x_l_c'], *zca), True, rnd['C_real'], pops)
@@ -152,6 +152,8 @@ def init_params(seed=0, dtype=np.float32):
             P[name] = np.ones(shape, dtype)
         else:
             P[name] = np.zeros(shape, dtype)
+    for name, shape in N.generator_moving_shapes():          # contrib batch_norm: moving_mean 0, moving_variance 1 (no random draw)
+        P[name] = (np.ones if name.endswith('variance') else np.zeros)(shape, dtype)
     for name, shape in N.classifier_param_shapes():
         if name.endswith('/V'):
             P[name] = (rng.standard_normal(shape) * 0.05).astype(dtype)
@@ -165,14 +167,22 @@ def init_params(seed=0, dtype=np.float32):
 SIZES = dict(B_G=100, L_C=50, U_C=50, L_D=20, U_D=80)
 
 
-def synth_batch(seed, sizes=SIZES, dtype=np.float32):
-    """SURVEY §8d synthetic CIFAR-shaped batch: class-prototype images in [-1,1]."""
+def synth_batch(seed, sizes=SIZES, dtype=np.float32, noise=0.25, mix=0.0):
+    """SURVEY §8d synthetic CIFAR-shaped batch: class-prototype images in [-1,1]; `noise` = pixel-noise sigma of the task.
+    mix > 0 (the non-saturating long-horizon fixture only, tests/golden/make_golden_long.py): every image is a blend
+    a*proto[y] + (1-a)*proto[y'] of its own class with a random OTHER class, a ~ U(1-mix, 1) — with mix = 0.5 images near a = 0.5 are
+    genuinely ambiguous, so the error rate has a floor above zero and depends on how well the decision boundaries are learnt."""
     rng = np.random.default_rng(seed)
     proto = np.random.default_rng(1234).uniform(-1, 1, (10, 32, 32, 3))
 
     def imgs(n):
         y = rng.integers(0, 10, n)
-        x = np.clip(proto[y] + 0.25 * rng.standard_normal((n, 32, 32, 3)), -1, 1)
+        base = proto[y]
+        if mix > 0:
+            other = (y + rng.integers(1, 10, n)) % 10
+            a = (1.0 - mix * rng.random(n)).reshape(n, 1, 1, 1)
+            base = a * base + (1.0 - a) * proto[other]
+        x = np.clip(base + noise * rng.standard_normal((n, 32, 32, 3)), -1, 1)
         return x.astype(dtype), np.eye(10, dtype=dtype)[y]
 
     b = {}

@@ -72,9 +72,25 @@ def _q(x):
     return bf16_round(x) if MFMA_BF16 else x
 
 
+# --------------------------------------------------------------------------
+# Summation-order control (tests/golden/make_golden_long.py): with SUM_REVERSED = True every contraction of a conv / transposed
+# conv / dense product and of their two gradients runs over its reduction index BACKWARDS (operands are copied reversed before the
+# BLAS call).  Mathematically the same numbers; in float32 a second, equally accurate rounding of each of them.  The long-horizon
+# fixtures use it to measure how far two correct float32 evaluations of the SAME free-running trajectory drift apart.
+# --------------------------------------------------------------------------
+SUM_REVERSED = False
+
+
+def _mm(a, b):
+    """a @ b over the reduction index in the order SUM_REVERSED selects."""
+    if SUM_REVERSED:
+        return np.ascontiguousarray(a[:, ::-1]) @ np.ascontiguousarray(b[::-1])
+    return a @ b
+
+
 def matmul(a, b):
     """a @ b with the operand rounding of the bf16 MFMA path when it is switched on (dense layers of the nets)."""
-    return _q(a) @ _q(b)
+    return _mm(_q(a), _q(b))
 
 
 def _chunks(n, per_image_elems):
@@ -97,7 +113,7 @@ def conv2d(x, w, stride=(1, 1), padding='SAME'):
     w2 = _q(w).reshape(kh * kw * ci, co)
     y = np.empty((n, ho, wo, co), x.dtype)
     for a, b in _chunks(n, ho * wo * kh * kw * c):
-        y[a:b] = (_patches(xp[a:b], kh, kw, sh, sw, ho, wo) @ w2).reshape(b - a, ho, wo, co)
+        y[a:b] = _mm(_patches(xp[a:b], kh, kw, sh, sw, ho, wo), w2).reshape(b - a, ho, wo, co)
     return y
 
 
@@ -111,7 +127,7 @@ def conv2d_bwd_filter(x, dy, wshape, stride=(1, 1), padding='SAME'):
     dy = _q(dy)
     dw = np.zeros((kh * kw * ci, co), x.dtype)
     for a, b in _chunks(n, ho * wo * kh * kw * c):
-        dw += _patches(xp[a:b], kh, kw, sh, sw, ho, wo).T @ dy[a:b].reshape(-1, co)
+        dw += _mm(_patches(xp[a:b], kh, kw, sh, sw, ho, wo).T, dy[a:b].reshape(-1, co))
     return dw.reshape(kh, kw, ci, co)
 
 
@@ -125,7 +141,7 @@ def conv2d_bwd_input(xshape, w, dy, stride=(1, 1), padding='SAME'):
     dy = _q(dy)
     w2t = _q(w).reshape(kh * kw * ci, co).T
     for a, b in _chunks(n, ho * wo * kh * kw * c):
-        dp = (dy[a:b].reshape(-1, co) @ w2t).reshape(b - a, ho, wo, kh, kw, ci)
+        dp = _mm(dy[a:b].reshape(-1, co), w2t).reshape(b - a, ho, wo, kh, kw, ci)
         for ky in range(kh):
             for kx in range(kw):
                 dxp[a:b, ky:ky + sh * ho:sh, kx:kx + sw * wo:sw, :] += dp[:, :, :, ky, kx, :]

@@ -56,6 +56,7 @@ class Train(Train_base):
         self._warm = False
         self._warm_keys = set()
         self.iteration = 0
+        self._exposed = None             # [(mark before, mark after)] of the waits for gradient buckets while measure_exposed(True)
         self.summary_train = self.summary_val = None
         if getattr(config, 'SUMMARY', False) and log_dir and self.rank == 0:          # :37-41
             from Training.Summary import Summary
@@ -111,9 +112,10 @@ class Train(Train_base):
             # The G-update that follows runs the generator on the same feed with the same (not yet updated) weights, and the
             # generator is deterministic (no dropout / noise): TF recomputes it in the second sess.run, here the forward
             # pass and its backward closures are kept for _g_forward_backward (bit-identical result, one G forward saved).
-            with cx.sub_tape(('good_generator',)) as g_tape:
+            g_replay = []
+            with cx.sub_tape(('good_generator',), replay=g_replay) as g_tape:
                 G = m.good_generator(self.z_g_ph, self.y_g_ph)
-            self._g_saved = (G, g_tape)
+            self._g_saved = (G, g_tape, g_replay)
             xz = concat_acts([m.as_image(self.x_u_c_ph), m.as_image(self.x_u_d_ph)])
             if m.zca() is not None:
                 xz = m.zca().apply(xz)
@@ -135,8 +137,10 @@ class Train(Train_base):
         with cx.phase_scope('G', train_nets=('good_generator',)):
             saved = getattr(self, '_g_saved', None)
             if saved is not None:                       # generator forward of the D-update on the same feed and weights
-                G, g_tape = saved
+                G, g_tape, g_replay = saved
                 self._g_saved = None
+                for fn in g_replay:                     # the state a re-executed forward pass would have advanced: batch-norm moving
+                    fn()                                # statistics get their second update of the iteration (the C-update makes the third)
             else:
                 G, g_tape = m.good_generator(self.z_g_ph, self.y_g_ph), None
             with cx.rng_scoped('G/D'):
@@ -280,8 +284,11 @@ class Train(Train_base):
         try:
             for i, (fn, grads, wait) in enumerate(segs):
                 if wait:                                    # this segment opens with an optimiser step: its network's buckets must be in
+                    mark = self._mark() if (self._exposed is not None and pending) else None
                     for wk in pending:
                         tgdist.wait_(wk)
+                    if mark is not None:
+                        self._exposed.append((mark, self._mark()))
                     pending = []
                 if use_graph and graphs[i] is not None:
                     lib.call('tg_graph_launch', graphs[i], cx.stream)
@@ -295,6 +302,30 @@ class Train(Train_base):
         self._warm_keys.add(key)       # graphs of a mode are captured from its SECOND iteration on: the first one allocates its buffers eagerly
         self.iteration += 1
 
+    # ---- how much of the gradient exchange is NOT hidden behind the backward pass (bench.py `exchange_exposed_ms`)
+    def _mark(self):
+        """a point of the launch stream's timeline: a timing event on a GPU (the waits are stream-side, the host does not block),
+        the host clock otherwise (gloo's wait blocks the host)."""
+        if self.cx.device.type == 'cuda':
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            return e
+        return time.perf_counter()
+
+    def measure_exposed(self, on=True):
+        """start (or stop) bracketing every wait for a network's gradient buckets in train_iteration."""
+        self._exposed = [] if on else None
+
+    def exposed_ms(self):
+        """total time the launch stream spent stalled in those waits since measure_exposed(True) — the exchange time the backward
+        pass did not hide.  Synchronises the device."""
+        if not self._exposed:
+            return 0.0
+        if isinstance(self._exposed[0][0], float):
+            return 1e3 * sum(b - a for a, b in self._exposed)
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in self._exposed))
+
     def _capture(self, segs, graphs, key):
         """Record every segment of one iteration as a hipGraph — all of them back to back, nothing launched and no collective issued
         in between.  Only reached when tg.dist.graphs_allowed(): the exchange backends used with graphs (rccl-direct, gloo) have no
@@ -303,6 +334,8 @@ class Train(Train_base):
         cx = self.cx
         cx.prep_cache = {}
         cx.plan_tag = key
+        for st in cx.stores.values():
+            st.frozen = True                     # the graphs hold these buffers' addresses: ParamStore.extend must not re-allocate them
         try:
             for i, (fn, _grads, _wait) in enumerate(segs):
                 if graphs[i] is not None:
@@ -322,6 +355,23 @@ class Train(Train_base):
     def losses(self):
         """(d_loss, g_loss, c_loss) of the last iteration — a device->host sync; call sparingly."""
         return tuple(float(v) for v in self.loss_dev.detach().cpu().numpy())
+
+    def training_statistics(self):
+        """The reference's end-of-epoch "Get the training statistics" run (:280-285): ONE forward-only sess.run of
+        [merged_summary_train, d_loss, g_loss, c_loss] on the epoch's LAST feed with train_ph = True.  One session call evaluates the
+        whole graph of Model.forward_pass once: a single set of fresh dropout / noise draws shared by the three losses (the training
+        iterations re-draw per solver run), every classifier application of forward_pass — C_real, C_unl, (C_unl_rep,) C_unl_d, C_fake —
+        updating pop_mean / the batch-norm moving statistics once more in call-site order, the generator's batch norm too; no
+        gradient, no optimiser step.  THESE losses are what the reference logs and writes to the train summary (:287-293), not the
+        last iteration's.  Returns (d_loss, g_loss, c_loss) as floats (a device->host sync)."""
+        cx = self.cx
+        with cx.phase_scope('stats', record=False):
+            PH = [self.z_g_ph, self.y_g_ph, self.x_l_c_ph, self.y_l_c_ph, self.x_l_d_ph, self.y_l_d_ph, self.x_u_d_ph, self.x_u_c_ph]
+            G, D, C = self.model.forward_pass(*PH, True)                                                       # :422
+            d, g, c = self._goodGAN_loss(G, D, C, None, [self.y_g_ph, self.y_l_c_ph], self.hyper[2:4], self.model.discriminator)
+            out = (float(d), float(g), float(c))
+        cx.rng.advance(cx)                       # the next iteration draws fresh numbers again
+        return out
 
     # ------------------------------------------------------------------ evaluation
     def _metric(self, real_lab_logits, real_lab, metric=None):
@@ -349,7 +399,7 @@ class Train(Train_base):
                     xa = m.zca().apply(m.as_image(xa))
                 with cx.rng_scoped('val/C'):
                     logits, _ = m.classifier(xa, False)
-                metric = self._metric(logits, ya, metric)[0]
+                metric = self._accuracy_metric(ya, logits, metric)[0]        # what _metric (:428-447) counts; its one-hot prediction output is not needed here
         return float(metric) if metric is not None else 0.0
 
     def sync_running_state(self):
@@ -410,9 +460,9 @@ class Train(Train_base):
                 self.feed(NNIO.next())
                 self.sample_latent()
                 self.train_iteration(pre_train=pre)
-            d_loss, g_loss, c_loss = self.losses()
             torch.cuda.synchronize()
             dt = time.time() - t0
+            d_loss, g_loss, c_loss = self.training_statistics() if iters > 0 else self.losses()        # :280-285
             init_op_val()
             self.sync_running_state()
             acc = self.evaluate(NNIO.val_batches())

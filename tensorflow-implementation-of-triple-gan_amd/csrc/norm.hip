@@ -687,6 +687,26 @@ __global__ void __launch_bounds__(256) bn_train_apply(const float* __restrict__ 
   }
 }
 
+// the moving-statistics chain of bn_train_apply alone (same arithmetic, same order), from the sums a forward launch left behind
+__global__ void __launch_bounds__(256) bn_moving_update(const double* __restrict__ sums, int c, SegTable st, float decay, float* __restrict__ mm,
+                                                        float* __restrict__ mv) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= c) return;
+  float m_run = mm[col], v_run = mv[col];
+  for (int s = 0; s < st.nseg; ++s) {
+    const double n = (double)st.rows[s];
+    double q0, q1;
+    bn_repl(sums, st.nseg, s, c, col, &q0, &q1);
+    const double mu = q0 / n;
+    double var = q1 / n - mu * mu;
+    var = var > 0. ? var : 0.;
+    const float vb = st.rows[s] > 1 ? (float)var * ((float)st.rows[s] / (float)(st.rows[s] - 1)) : (float)var;
+    m_run = m_run * decay + (float)mu * (1.f - decay);
+    v_run = v_run * decay + vb * (1.f - decay);
+  }
+  mm[col] = m_run; mv[col] = v_run;
+}
+
 __global__ void __launch_bounds__(256) bn_train_bwd_apply(const float* __restrict__ dy, int ld_dy, const float* __restrict__ x, int ld_x,
                                                           float* __restrict__ dx, int ld_dx, int c, SegTable st, int chunk,
                                                           const double* __restrict__ sums, const float* __restrict__ gamma,
@@ -1013,6 +1033,20 @@ int tg_bn_train_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int 
   TG_CHECK_LAUNCH("bn_sums");
   hipLaunchKernelGGL(bn_train_apply, grid, dim3(256), 0, s, x, ld_x, y, ld_y, c, st, chunk, sums, gamma, beta, eps, decay, moving_mean, moving_var, mean_inv);
   TG_CHECK_LAUNCH("bn_train_apply");
+  return TG_OK;
+}
+
+int tg_bn_moving_update_f32(const double* sums, int rows, int c, const int32_t* seg_rows, int nseg, float decay, float* moving_mean,
+                            float* moving_var, void* stream) {
+  SegTable st;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(sums && moving_mean && moving_var, "bn_moving_update: null buffer");
+  TG_REQUIRE(c > 0, "bn_moving_update: c=%d", c);
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 16.0 * c, s);
+  hipLaunchKernelGGL(bn_moving_update, dim3((c + 255) / 256), dim3(256), 0, s, sums, c, st, decay, moving_mean, moving_var);
+  TG_CHECK_LAUNCH("bn_moving_update");
   return TG_OK;
 }
 

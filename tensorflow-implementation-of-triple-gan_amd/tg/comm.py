@@ -117,19 +117,43 @@ class Communicator(object):
             self.handle = C.c_void_p()
 
 
-def exchange_id(world, rank, make_id, key='tg_comm_id'):
+def exchange_id(world, rank, make_id, key='tg_comm_id', timeout=None):
     """Rendezvous only: rank 0 calls make_id() and publishes the bytes in a TCPStore at MASTER_ADDR:MASTER_PORT, every rank
     reads them.  Under torchrun the elastic agent already serves a store on that port (TORCHELASTIC_USE_AGENT_STORE=True): every
-    rank then connects as a client, exactly as torch's own env:// rendezvous does.  Returns (id bytes, store)."""
+    rank then connects as a client, exactly as torch's own env:// rendezvous does.  Returns (id bytes, store).
+
+    Bounded (TG_RENDEZVOUS_TIMEOUT seconds, default 300): every rank announces itself under '<prefix>/here/<rank>'; when the time is
+    up, rank 0 fails with the list of ranks that never arrived and the other ranks with "rank 0 did not publish" — instead of a
+    communicator initialisation that hangs on a rank that is not there."""
     import datetime
     import torch.distributed as dist
+    timeout = float(os.environ.get('TG_RENDEZVOUS_TIMEOUT', '300')) if timeout is None else float(timeout)
     addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
     port = int(os.environ.get('MASTER_PORT', '29500'))
     agent = os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True'
-    store = dist.TCPStore(addr, port, world, is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=300))
-    key = '%s/%s' % (os.environ.get('TORCHELASTIC_RUN_ID', 'run'), key)
+    try:
+        store = dist.TCPStore(addr, port, world, is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=timeout),
+                              wait_for_workers=False)
+    except Exception as e:
+        raise lib.TgError("rank %d of %d: no rendezvous store at %s:%d within %.0f s (%s)" % (rank, world, addr, port, timeout, e))
+    # the agent's store outlives a restarted worker group: key the id by the incarnation, or ranks of the new group could read the
+    # communicator id of the dead one before rank 0 has overwritten it
+    prefix = '%s/%s' % (os.environ.get('TORCHELASTIC_RUN_ID', 'run'), os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'))
+    key = '%s/%s' % (prefix, key)
+    here = lambda r: '%s/here/%d' % (prefix, r)
+    store.set(here(rank), b'1')
     if rank == 0:
         store.set(key, make_id())
+        try:
+            store.wait([here(r) for r in range(world)], datetime.timedelta(seconds=timeout))
+        except Exception:
+            missing = [r for r in range(world) if not store.check([here(r)])]
+            raise lib.TgError("rendezvous at %s:%d: rank(s) %s of %d did not arrive within %.0f s" % (addr, port, missing, world, timeout))
+    try:
+        store.wait([key], datetime.timedelta(seconds=timeout))
+    except Exception:
+        raise lib.TgError("rendezvous at %s:%d: rank 0 did not publish the communicator id within %.0f s (rank %d of %d waiting)"
+                          % (addr, port, timeout, rank, world))
     return store.get(key), store
 
 

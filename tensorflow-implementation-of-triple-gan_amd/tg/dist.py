@@ -176,6 +176,44 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def minmax_over_ranks(values, device):
+    """(min, max) over the replicas of each entry of `values` (floats exactly representable in float64) — one max-all-reduce of
+    [v, -v].  What bench.py's `replicas_identical` is computed from."""
+    v = torch.tensor([float(x) for x in values], dtype=torch.float64, device=device)
+    t = torch.cat([v, -v])
+    if active():
+        if _direct is not None:
+            _on_xstream(lambda s: _direct.allreduce_max_f64_(t, stream=s)).wait()
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = t.cpu()
+    n = len(values)
+    return [-float(x) for x in t[n:]], [float(x) for x in t[:n]]
+
+
+def self_test(device, n=4096):
+    """Start-up check of the exchange every replica is about to rely on: a sum-all-reduce of a vector holding rank + 1 must give
+    world (world + 1) / 2 in every element on every rank, and a broadcast from rank 0 must arrive.  Raises RuntimeError naming what
+    failed; returns the number of ranks that took part (1 without replicas)."""
+    if not active():
+        return 1
+    w, r = world_size(), rank()
+    t = torch.full((n,), float(r + 1), dtype=torch.float32, device=device)
+    allreduce_sum_(t)
+    want = w * (w + 1) / 2.0
+    bad = int((t != want).sum().item())
+    if bad:
+        raise RuntimeError("exchange self-test: sum-all-reduce over %d ranks gave %r in %d of %d elements on rank %d, expected %r "
+                           "(backend %s)" % (w, float(t[0].item()), bad, n, r, want, backend_name()))
+    b = torch.full((n,), float(1000 + r), dtype=torch.float32, device=device)
+    broadcast_(b, 0)
+    if torch.device(device).type == 'cuda':
+        torch.cuda.synchronize()
+    if float(b.min().item()) != 1000.0 or float(b.max().item()) != 1000.0:
+        raise RuntimeError("exchange self-test: broadcast from rank 0 did not arrive on rank %d" % r)
+    return w
+
+
 def barrier():
     if active():
         if _direct is not None:                      # a one-element sum every rank must reach, then drain the device

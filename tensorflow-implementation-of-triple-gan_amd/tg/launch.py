@@ -1,8 +1,10 @@
 """One process per GPU without an external launcher: `spawn_ranks` starts N fresh children of a script with RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what `python -m torch.distributed.run` would export) and waits for them.
 
-The parent must not have initialised the GPU (it only counts devices), it never replaces itself with another program, children are
-stopped by their exact PIDs, and a failed rank makes the whole job exit non-zero."""
+The parent never touches HIP: devices are counted from the kernel's topology files (sysfs), not through torch / hipGetDeviceCount
+(which opens /dev/kfd in the launcher — a process that then starts N children must not hold the GPU).  It never replaces itself with
+another program, children are stopped by their exact PIDs, and a failed rank makes the whole job exit non-zero."""
+import glob
 import os
 import socket
 import subprocess
@@ -18,16 +20,77 @@ def free_port():
     return port
 
 
-def visible_devices():
-    """number of HIP devices this process would see; counting does not initialise the GPU."""
-    import torch
-    return torch.cuda.device_count()
+KFD_NODES = '/sys/class/kfd/kfd/topology/nodes'
+
+
+def _visible_filter(n, env):
+    """apply HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (comma lists of indices or UUIDs; an empty string
+    hides every device, an out-of-range index ends the list — the runtime's rule)."""
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = env.get(var)
+        if v is None:
+            continue
+        keep = 0
+        for tok in [t.strip() for t in v.split(',')] if v.strip() else []:
+            if tok.isdigit():
+                if int(tok) >= n:
+                    break
+                keep += 1
+            elif tok:                 # a UUID ("GPU-...") names one device
+                keep += 1
+        n = min(n, keep)
+    return n
+
+
+def visible_devices(env=None, nodes_dir=None, render_glob='/dev/dri/renderD*'):
+    """Number of GPUs a child process would see, WITHOUT any HIP / HSA call in this process: KFD topology nodes with simd_count > 0
+    (CPU nodes have 0), capped by the render nodes present in /dev/dri (a container sees the host's whole topology but only the
+    device files passed through to it; the render nodes alone when the topology is not mounted), then the *_VISIBLE_DEVICES filters.
+    An over-count is harmless — every rank checks its own device in tg.dist.init() and fails the job — an under-count is not."""
+    env = os.environ if env is None else env
+    nodes_dir = KFD_NODES if nodes_dir is None else nodes_dir
+    n = 0
+    found = False
+    for prop in glob.glob(os.path.join(nodes_dir, '*', 'properties')):
+        try:
+            with open(prop) as f:
+                for line in f:
+                    parts = line.split()
+                    if len(parts) == 2 and parts[0] == 'simd_count':
+                        found = True
+                        if int(parts[1]) > 0:
+                            n += 1
+        except OSError:
+            continue
+    render = len(glob.glob(render_glob))
+    if not found:
+        n = render
+    elif render:
+        n = min(n, render)
+    return _visible_filter(n, env)
+
+
+def holds_gpu():
+    """True when this process has the GPU driver's device file open (any HIP call does that) — spawn_ranks refuses to fork then."""
+    try:
+        for fd in os.listdir('/proc/self/fd'):
+            try:
+                if os.readlink('/proc/self/fd/' + fd) == '/dev/kfd':
+                    return True
+            except OSError:
+                continue
+    except OSError:
+        pass
+    return False
 
 
 def spawn_ranks(n, argv, env=None, need_devices=True, poll=0.2):
     """Run `python argv...` as ranks 0..n-1 on 127.0.0.1.  Rank 0 inherits stdout (its one JSON line goes straight through); every
     rank inherits stderr.  Returns the job's exit code: 0 when every rank exited 0, else the first non-zero one (the other ranks
     are terminated as soon as one fails — a collective they wait in would never complete)."""
+    if holds_gpu():
+        sys.stderr.write("tg.launch: this process has already initialised the GPU (/dev/kfd is open); start ranks from a process that has not\n")
+        return 2
     if need_devices:
         have = visible_devices()
         if have < n:

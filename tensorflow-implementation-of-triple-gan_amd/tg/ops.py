@@ -378,6 +378,12 @@ def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_g
     y = cx.new_act(x.n, x.h, x.w, c, x.ld, requires_grad=needs)
     _call('tg_bn_train_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, seg_array(seg_rows), nseg, _p(gamma), _p(beta), eps, decay, _p(mm), _p(mv),
           _p(sums), zd, _p(mean_inv), cx.stream)
+    if cx.state_replay is not None and mm is not None:
+        # this forward pass is being KEPT for a later solver run that TensorFlow would re-execute (Context.sub_tape(replay=...)): the
+        # re-execution's only lasting effect is one more moving-statistics update from the same batch sums
+        rows_total = x.rows
+        cx.state_replay.append(lambda: _call('tg_bn_moving_update_f32', _p(sums), rows_total, c, seg_array(seg_rows), nseg, decay, _p(mm), _p(mv),
+                                             cx.stream))
     if not needs:
         return y
 

@@ -85,6 +85,7 @@ class ParamStore(object):
         self._narrow()
         self.step = torch.zeros(1, dtype=torch.int32, device=device)
         self.ema = None
+        self.frozen = False          # set by Train._capture: a hipGraph holds this store's device pointers, re-allocation is an error
 
     def _narrow(self):
         f = self._full
@@ -155,6 +156,10 @@ class ParamStore(object):
         for k, buf in list(self._full.items()):
             need = self.n_s if k == 's' else self.n_p
             if buf.numel() < need:                     # beyond the reserve: re-allocate with room to double (pointers change)
+                if self.frozen:
+                    raise lib.TgError("ParamStore %r: variable(s) %s created after a hipGraph captured this store's device pointers and "
+                                      "beyond its reserve (%d > %d floats): create every variable before the first Train.train_iteration"
+                                      % (self.name, [nm for nm, _, _ in specs], need, buf.numel()))
                 new = torch.zeros(max(need, 2 * buf.numel()), dtype=buf.dtype, device=buf.device)
                 new[:buf.numel()].copy_(buf)
                 self._full[k] = new
@@ -295,6 +300,7 @@ class Context(object):
         self._prep_rec = None
         self.tail_jobs = []            # deferred filter-gradient tails of the running backward pass (ops.filter_grad / flush_tails)
         self.prep_cache = None         # {layout key: prepared filter buffers} while Train.train_iteration runs (see ops.conv2d)
+        self.state_replay = None       # list collecting state-update closures of a kept forward pass (sub_tape(replay=...))
         self._zarena = {}              # phase -> dict(sizes=[...], buf=tensor or None, cursor=int, recording=bool)
         self._events = {}
         self._side_depth = 0
@@ -482,16 +488,18 @@ class Context(object):
             self.phase, self.counter, self.tape, self.train_nets = prev
 
     @contextlib.contextmanager
-    def sub_tape(self, train_nets):
+    def sub_tape(self, train_nets, replay=None):
         """record the ops executed inside on a SEPARATE tape (returned) with their own trainable set: lets one solver run
-        keep a forward pass (and its backward closures) for the next run to finish."""
-        prev = (self.tape, self.train_nets)
+        keep a forward pass (and its backward closures) for the next run to finish.  replay: a list that collects, from the ops
+        executed inside, closures re-applying the STATE updates a re-execution of this forward pass would make (batch-norm moving
+        statistics) — the run that re-uses the pass calls them where TensorFlow would have run the pass again."""
+        prev = (self.tape, self.train_nets, self.state_replay)
         tape = []
-        self.tape, self.train_nets = tape, set(train_nets)
+        self.tape, self.train_nets, self.state_replay = tape, set(train_nets), replay
         try:
             yield tape
         finally:
-            self.tape, self.train_nets = prev
+            self.tape, self.train_nets, self.state_replay = prev
 
     @contextlib.contextmanager
     def no_record(self):
@@ -557,6 +565,9 @@ class Context(object):
             st.extend([(full, tuple(int(d) for d in shape), trainable)])
             val = initializer(tuple(shape)) if callable(initializer) else np.full(shape, initializer, np.float32)
             st.set(full, val)
+            if trainable and st.ema is not None:        # tf.train.ExponentialMovingAverage starts a shadow at the variable's initial value
+                kind, off, n, _ = st.index[full]
+                st.ema[off:off + n].copy_(st.p[off:off + n])
         # the same bytes may be declared under two views (the classifier's first filter: [3,3,3,128] = [27,128])
         assert int(np.prod(st.shape(full))) == int(np.prod(shape)), (full, st.shape(full), shape)
         return st.value(full)

@@ -21,22 +21,17 @@ def inverse_transform(images):
 
 
 def merge(images, size):
-    """utils.py:195-207: tile [N,h,w,c] into a size[0] x size[1] grid."""
-    h, w = images.shape[1], images.shape[2]
-    if images.shape[3] in (3, 4):
-        c = images.shape[3]
-        img = np.zeros((h * size[0], w * size[1], c))
-        for idx, image in enumerate(images):
-            i, j = idx % size[1], idx // size[1]
-            img[j * h:j * h + h, i * w:i * w + w, :] = image
-        return img
-    if images.shape[3] == 1:
-        img = np.zeros((h * size[0], w * size[1]))
-        for idx, image in enumerate(images):
-            i, j = idx % size[1], idx // size[1]
-            img[j * h:j * h + h, i * w:i * w + w] = image[:, :, 0]
-        return img
-    raise ValueError('in merge(images,size) images parameter must have dimensions: HxW or HxWx3 or HxWx4')
+    """Tile [N,h,w,c] (c in 1, 3, 4) row-major into a size[0] x size[1] grid — the result of utils.py:195-207, as one reshape /
+    transpose; grid cells beyond N stay zero; single-channel grids come back 2-D."""
+    images = np.asarray(images)
+    n, h, w, c = images.shape
+    if c not in (1, 3, 4):
+        raise ValueError('merge: images must be [N,H,W,1], [N,H,W,3] or [N,H,W,4], got %r' % (images.shape,))
+    rows, cols = int(size[0]), int(size[1])
+    cells = np.zeros((rows * cols, h, w, c), np.float64)
+    cells[:min(n, rows * cols)] = images[:rows * cols]
+    grid = cells.reshape(rows, cols, h, w, c).transpose(0, 2, 1, 3, 4).reshape(rows * h, cols * w, c)
+    return grid[:, :, 0] if c == 1 else grid
 
 
 def write_png(path, img):

@@ -166,6 +166,9 @@ def test_synchronised_iteration(data, prec, oracle_prec):
     g_ref = S.g_phase(st, data, b64, r64['G'], hyper)
     tr._g_forward_backward()
     check_grads(stores['good_generator'], st['last_grads']['G'], tol=tol)
+    gs = stores['good_generator']
+    for k in gs.names(False):                      # the G-update re-uses the D-update's generator forward and re-applies the moving-
+        assert G.rel_err(gs.get(k), st['P'][k]) < tol['stat'], k   # statistics update TF's second execution makes (modle_base.py:229-237)
     tr._train_op(tr.g_optimizer, stores['good_generator'])
     for net in NETS.values():
         sync(net)

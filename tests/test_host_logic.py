@@ -121,6 +121,22 @@ def test_param_store_layout_and_roundtrip():
     assert set(d) == {'net/a', 'net/pop', 'net/b'}
 
 
+def test_param_store_growth_keeps_pointers_inside_the_reserve_and_refuses_to_move_captured_buffers():
+    """advisor (round 2): variables appended within the reserve keep every device pointer; beyond it the buffers move, which is an
+    error once a hipGraph has captured them (ParamStore.frozen, set by Train._capture)."""
+    import torch
+    from tg import lib
+    from tg.runtime import ParamStore
+    st = ParamStore('net', [('net/a', (8,), True)], torch.device('cpu'), capacity=64)
+    st.enable_ema()
+    ptr = st.p.data_ptr()
+    st.extend([('net/b', (40,), True)])                               # 32 + 64 floats needed, 96 reserved
+    assert st.p.data_ptr() == ptr and st.n_p == 96 and st.ema.numel() == 96
+    st.frozen = True
+    with pytest.raises(lib.TgError, match='after a hipGraph captured'):
+        st.extend([('net/c', (64,), True)])
+
+
 def test_model_param_specs_match_reference_counts():
     from Model.Good_GAN_cifar10 import Good_GAN_cifar10
     specs = Good_GAN_cifar10.param_specs()

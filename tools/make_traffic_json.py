@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """After tools/pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, separate, no trace domains): write the HBM-traffic
 record bench.py's `roofline.traffic` is read from.  The record carries the sha256 of the kernel sources it was collected for (csrc/igemm.hip +
-csrc/conv3x3_bf16.hip, concatenated); bench.py reports traffic = null for any other source (a stale figure is worse than none).
+csrc/conv3x3_bf16.hip + csrc/wgrad3x3.hip, concatenated); bench.py reports traffic = null for any other source (a stale figure is worse than none).
 
     python tools/make_traffic_json.py [gpurun_out/traffic] [round tag] > profiles/<round>_traffic.json
 """
@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 root = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/traffic'
-tag = sys.argv[2] if len(sys.argv) > 2 else 'r02'
+tag = sys.argv[2] if len(sys.argv) > 2 else 'r03'
 vals = collections.defaultdict(lambda: {'FETCH_SIZE': [], 'WRITE_SIZE': []})
 for kind in ('fetch', 'write'):
     paths = sorted(glob.glob('%s/%s/*/*counter_collection.csv' % (root, kind)), key=os.path.getmtime)[-1:]
@@ -51,11 +51,13 @@ M, C = 250 * 32 * 32, 128
 alg_fwd = 4 * (M * C + M * C + C * 9 * C)                       # input + output + filter, fp32
 dom = entry('conv3x3_pipe_kernel<32, true, false>', 256, min_write_kb=100000)      # the 250-image launches (131 MB written); the 128-image heads of split launches share the grid
 CSRC = os.path.join(ROOT, 'tensorflow-implementation-of-triple-gan_amd', 'csrc')
+SOURCES = ('igemm.hip', 'conv3x3_bf16.hip', 'wgrad3x3.hip')        # every kernel bench.py's roofline object names (bench.TRAFFIC_SOURCES)
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace domains) on `python3 bench.py --steps 3 --warmup 2 --no-graph`, "
               "round %s, one MI355X; tools/pmc_traffic.sh + tools/make_traffic_json.py" % tag,
     "units": "counter values are KB; gfx950 correction of MI355X_MICROARCH.md §HBM: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced streams -> x2; WRITE_SIZE exact",
-    "kernel_sources_sha256": hashlib.sha256(open(os.path.join(CSRC, 'igemm.hip'), 'rb').read() + open(os.path.join(CSRC, 'conv3x3_bf16.hip'), 'rb').read()).hexdigest(),
+    "kernel_source_files": list(SOURCES),
+    "kernel_sources_sha256": hashlib.sha256(b''.join(open(os.path.join(CSRC, f), 'rb').read() for f in SOURCES)).hexdigest(),
 }
 if dom:
     n_act = 12.0 / 30.0                                          # share of tg_igemm_actsum launches (they also read the producing layer's activation)
