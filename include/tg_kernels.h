@@ -83,16 +83,30 @@ typedef struct tg_igemm_desc {
                                   * 4 * n_group columns (zero weights for the taps a parity does not have) instead of four unequal ones. */
 } tg_igemm_desc;
 
+/* Scratch of the MFMA launches (every tg_igemm_* entry point takes `scratch, scratch_bytes` in front of `stream`): device memory the
+ * launch may overwrite, OWNED BY THE CALLER — the library never allocates device memory — 16-byte aligned, free for reuse once the launch
+ * has completed on `stream` (launches on concurrent streams need their own).  tg_igemm_workspace_bytes answers, on the host, how much a
+ * launch of these descriptors can use (seg_rows / nseg as passed to tg_igemm_colsum_* / _actsum_*, nseg = 0 otherwise; bf16: the
+ * *_bf16 entry point; < 0 on a bad descriptor).  Two users:
+ *   - the generic kernel cuts the tiles of the last partial round of resident workgroups (1 128 tiles on 512 slots), of an under-filled
+ *     launch (225 tiles) or of the long sub-problems of a stride-2 launch (9 / 6 / 6 / 4 taps) along K; the partial sums pass through the
+ *     scratch and a second launch adds them up in a fixed order (deterministic) and runs the epilogue.  OPTIONAL: with scratch == NULL or
+ *     fewer bytes than the answer the launch runs one workgroup per tile (the round-2 schedule) — same result to fp32 summation order;
+ *   - the halo-tiled 3x3 kernel packs the bf16 filter there and reads it back by LDS-DMA (tg_igemm_*_bf16 on a layer of that kernel's
+ *     shape).  REQUIRED: such a launch with less scratch than the answer fails with TG_ERR_INVALID — it does not take another kernel. */
+int64_t tg_igemm_workspace_bytes(const tg_igemm_desc* descs, int n_desc, const int32_t* seg_rows, int nseg, int bf16);
+
 /* out[p,n] = act( sum_t sum_c in[pix(p,t),c] * w[n,t,c] + bias[n] ).
  * Replaces tf.nn.conv2d / tf.layers.conv2d (Model/nn.py:504, Model/modle_base.py:102,161), their
  * input-gradient, tf.layers.conv2d_transpose (Model/modle_base.py:250; one launch per output parity),
  * tf.matmul / tf.layers.dense (Model/nn.py:553, Model/modle_base.py:40) and the ZCA matmul
  * (Model/Good_GAN_cifar10.py:296).  bias may be NULL. */
-int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* stream);
+int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* scratch, int64_t scratch_bytes,
+                 void* stream);
 /* up to 4 sub-problems in ONE launch (the output parities of a stride-2 transposed conv / strided-conv input-gradient):
  * same buffers, M, N and gathered tensor; each descriptor brings its own taps and output offsets. */
 int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,
-                       void* stream);
+                       void* scratch, int64_t scratch_bytes, void* stream);
 
 /* tg_igemm_f32 (no bias, no activation) that also accumulates the per-(application segment, channel) sums of its output
  * into colsum[nseg][c_out] (fp64; zeroed by the call unless colsum_zeroed != 0 — the caller then guarantees zeros, e.g. one
@@ -100,7 +114,7 @@ int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const float* in, 
  * (Model/nn.py:171-175) fused into the convolution.  seg_rows: HOST array, at most 8 entries; a tile may straddle one
  * application boundary, so every entry must be at least the row count of some tile that divides c_out (32 ... 128). */
 int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
-                        double* colsum, int colsum_zeroed, void* stream);
+                        double* colsum, int colsum_zeroed, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* Input gradient of a convolution whose INPUT was produced by a mean-only-BN layer with nonlinearity `act`: the same launch as
  * tg_igemm_colsum_f32 (d = the input-gradient geometry, in = dpre of this conv, w = padded HWIO filter), but every output element is
@@ -109,9 +123,9 @@ int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w,
  * Together with tg_mobn_center_f32 this replaces tg_mobn_bwd_f32 for that producing layer (its gradient never makes a separate
  * statistics pass). */
 int tg_igemm_actsum_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* yact, int act, float alpha, float* out,
-                        const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* stream);
+                        const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* scratch, int64_t scratch_bytes, void* stream);
 int tg_igemm_actsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* yact, int act, float alpha, float* out,
-                         const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* stream);
+                         const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* filter gradient, split over `n_split` pixel ranges:
  * slab[s][t][c][n] = sum_{p in split s} in[pix(p,t),c] * dout[p,n]   (c < ld_in, n < c_out).
@@ -120,15 +134,16 @@ int tg_igemm_actsum_bf16(const tg_igemm_desc* d, const float* in, const float* w
  * slab holds n_split*n_taps*ld_in*c_out floats; deterministic (no atomics). */
 int tg_wgrad_f32(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream);
 
-/* bf16 MFMA variants of the four launches above (BASELINE.json configs[3], "bf16 MFMA conv path"): identical arguments,
- * tensors stay fp32 in HBM; every MFMA operand (gathered activation, filter, output gradient) is rounded to bf16
- * (round-to-nearest-even) inside the kernel and the products accumulate in fp32 (v_mfma_f32_32x32x16_bf16).  Bias,
- * activation, statistics and the stored result are fp32. */
-int tg_igemm_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* stream);
+/* bf16 MFMA variants of the four launches above (BASELINE.json configs[3], "bf16 MFMA conv path"): identical arguments; tensors stay
+ * fp32 in HBM; every MFMA operand (gathered activation, filter, output gradient) is rounded to bf16 (round-to-nearest-even) inside
+ * the kernel and the products accumulate in fp32 (v_mfma_f32_32x32x16_bf16).  Bias, activation, statistics and the stored result are
+ * fp32. */
+int tg_igemm_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* scratch, int64_t scratch_bytes,
+                  void* stream);
 int tg_igemm_multi_bf16(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,
-                        void* stream);
+                        void* scratch, int64_t scratch_bytes, void* stream);
 int tg_igemm_colsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
-                         double* colsum, int colsum_zeroed, void* stream);
+                         double* colsum, int colsum_zeroed, void* scratch, int64_t scratch_bytes, void* stream);
 int tg_wgrad_bf16(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream);
 
 /* ---- descriptor builders and workspace sizes (host code, no device work) -------------------------------------------------------

@@ -104,6 +104,88 @@ bool igemm_pick_tile(const tg_igemm_desc* descs, int n_desc, bool colsum, const 
   return true;
 }
 
+void igemm_sub_order(const tg_igemm_desc* descs, int n_desc, int* order) {
+  for (int i = 0; i < n_desc; ++i) order[i] = i;
+  for (int i = 0; i < n_desc; ++i)
+    for (int j = i + 1; j < n_desc; ++j)
+      if (descs[order[j]].n_taps > descs[order[i]].n_taps) { int t_ = order[i]; order[i] = order[j]; order[j] = t_; }
+}
+
+// ---- work units: which tiles are cut along K -----------------------------------------------------------------------------------------
+// Why: (a) a launch of fewer tiles than resident-workgroup slots (2 per compute unit) leaves compute units idle or with ONE workgroup,
+// whose load / LDS / barrier stalls nothing hides (measured: 225 tiles, 200 K-tiles each, 0.151 ms; cut in two 0.125 ms; the 32-tile
+// tail of a split 130-image classifier launch 0.058 -> 0.022 ms); (b) the 9 / 6 / 6 / 4-tap parities of a stride-2 transposed conv are
+// resident together and the 9-tap workgroups finish last (0.146 -> 0.120 ms with the 9-tap tiles cut in two).  The price is the partial
+// sums' round trip through scratch and a fix-up launch (~10 us end to end), so short launches and launches that fill the chip anyway are
+// left alone.  MEASURED AND REJECTED (round 3, profiles/r03_split_ab.txt): cutting only the tiles of the last partial round of a launch
+// with more tiles than slots (1 128 tiles of conv3: 0.231 -> 0.272 ms) — workgroups do not run in lockstep rounds, a compute unit whose
+// partner slot is empty runs the remaining workgroup faster, and the fix-up launch waits for the whole main launch.
+static const bool g_no_split = getenv("TG_IGEMM_NOSPLIT") != nullptr;      // A/B switch, read once at library load
+
+void igemm_schedule(int n_sub, const int* nk, int64_t T, int bm, int bn, int slots, bool allow_split, IgemmSched* o) {
+  std::memset(o, 0, sizeof *o);
+  for (int s = 0; s < 4; ++s) o->ks[s] = 1;
+  if (slots < 1) slots = 512;
+  // one K-tile (32 deep) of a bm x bn tile on one of `slots` workgroup slots of a 157 TFLOP/s chip, in microseconds
+  const double ktile_us = 2.0 * bm * bn * 32 / (157.3e12 / slots) * 1e6;
+  int mink = (int)(8.0 / ktile_us + 0.999);                // a unit is at least ~8 us of matrix work
+  if (mink < 2) mink = 2;
+  const bool split_ok = allow_split && !g_no_split && T > 0;
+  if (n_sub == 1) {
+    const int K = nk[0];
+    o->nfull = (int)T;
+    o->n_units = (int)T;
+    // under-filled launches only: all units resident at once; few tiles (a quarter of the slots) or a long reduction (>= 100 K-tiles) —
+    // 200-250 tiles of 27-45 K-tiles measured neutral to -15 %
+    if (!split_ok || T * 2 > slots || !(T * 4 <= slots || K >= 100)) return;
+    int ks = (int)(slots / T);
+    if (ks > 8) ks = 8;
+    while (ks > 1 && K / ks < mink) --ks;
+    if (ks < 2) return;
+    o->ks[0] = ks;
+    o->nfull = 0;
+    o->n_fix = (int)T;
+    o->n_units = (int)(T * ks);
+    o->ws_bytes = T * ks * (int64_t)bm * bn * 4;
+    return;
+  }
+  // several sub-problems: every tile index owns one unit per (sub-problem, K segment).  Cut only while everything stays resident
+  // (T * sum ks <= slots): bring the long sub-problems' units down towards the shortest one's length.
+  int best_ks[4] = {1, 1, 1, 1};
+  if (split_ok && T * n_sub <= slots) {
+    int shortest = nk[0];
+    for (int s = 1; s < n_sub; ++s) shortest = nk[s] < shortest ? nk[s] : shortest;
+    for (;;) {
+      int longest = 0, ls = -1, sum = 0;
+      for (int s = 0; s < n_sub; ++s) {
+        sum += best_ks[s];
+        const int len = (nk[s] + best_ks[s] - 1) / best_ks[s];
+        if (len > longest) { longest = len; ls = s; }
+      }
+      if (ls < 0 || best_ks[ls] >= 4 || T * (sum + 1) > slots || sum + 1 > 16) break;
+      if (nk[ls] / (best_ks[ls] + 1) < mink || longest * 4 <= shortest * 5) break;      // already within 25 % of the shortest
+      ++best_ks[ls];
+    }
+  }
+  int len = 0, nslot = 0, nsp = 0;
+  for (int s = 0; s < n_sub; ++s) {
+    o->ks[s] = best_ks[s];
+    if (best_ks[s] > 1) { o->split_sub[nsp] = (int8_t)s; o->first_slot[nsp] = (int8_t)nslot; ++nsp; }
+    for (int k = 0; k < best_ks[s]; ++k) {
+      o->pat_sub[len] = (int8_t)s; o->pat_k[len] = (int8_t)k;
+      o->pat_slot[len] = best_ks[s] > 1 ? (int8_t)nslot++ : (int8_t)-1;
+      ++len;
+    }
+  }
+  o->pat_len = len;
+  o->n_pat_split = nslot;
+  o->n_split_sub = nsp;
+  o->nfull = (int)T;
+  o->n_units = (int)(T * len);
+  o->n_fix = (int)(T * nsp);
+  o->ws_bytes = T * nslot * (int64_t)bm * bn * 4;
+}
+
 static const int g_tuning_loaded = (igemm_tuning_from_env(), 0);      // at library load: never a getenv on the launch path
 
 // widest tile that divides the dimension; odd multiples of 32 from 160 on (288 = 256 + 32 label channels, 544, 160) take 64-wide tiles with

@@ -23,6 +23,7 @@
 //  * workgroup order is XCD-aware in both kernels (tiles that share operand rows meet in one XCD's L2).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include "tg_common.h"
 #include "tg_device.h"
 #include "tg_geom.h"
@@ -100,6 +101,18 @@ struct IgemmParams {
   int ymul_act;
   float ymul_alpha;
   int nseg, seg_rows[8];
+  // ---- work units (tg::igemm_schedule, geom.cpp).  A unit is one output tile over a K range; tiles whose K range is cut into ks > 1
+  // units leave raw partial accumulators in `ws` and are finished by the fix-up launch (same kernel, FIXUP = true).
+  int n_units;                    // grid of the main launch
+  int n_fix;                      // grid of the fix-up launch (tiles that were cut), 0: none
+  int nfull;                      // pat_len == 0 (one sub-problem): tiles [0, nfull) are whole, tiles [nfull, T) are cut into ks[0] units
+  int ks[MAX_SUB];                // units per tile of each sub-problem
+  int pat_len;                    // > 0: every tile index owns pat_len consecutive units, unit w of the pattern = (sub, K segment)
+  int n_pat_split;                // pattern entries that are partial (per tile index: that many ws slots)
+  int n_split_sub;                // sub-problems with ks > 1 (fix-up grid = tiles * n_split_sub)
+  int8_t pat_sub[16], pat_k[16], pat_slot[16];      // pat_slot: ws slot of the entry inside its tile index's group, -1: whole tile
+  int8_t split_sub[MAX_SUB], first_slot[MAX_SUB];   // the i-th cut sub-problem and the slot of its first K segment
+  float* ws;
 };
 
 
@@ -121,7 +134,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool COLSUM, bool BF16>
+// FIXUP = true: the second launch of a schedule with cut tiles — no K loop: the accumulators are the sum (in K-segment order, so
+// deterministic) of the partials the main launch left in p.ws, then the SAME epilogue.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool COLSUM, bool BF16, bool FIXUP = false>
 __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
@@ -140,19 +155,43 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   STAMP(t_entry);
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int per_sub = p.m_tiles * p.n_tiles;
-  const int lid = xcd_remap(blockIdx.x, per_sub * p.n_sub);
-  // Several sub-problems (the 9/6/6/4-tap parities of a stride-2 transposed conv): tile-major, sub-problem-minor, and the order of
-  // the sub-problems rotates every 32 workgroups.  Workgroups go to the 32 compute units of an XCD round-robin, all resident at once
-  // for these small launches, so with a fixed order unit j would get sub-problem j % n_sub every time (measured: the units holding
-  // only 9-tap workgroups finish at 190 us, the median at 100); rotating gives every unit the same mix.
-  int sub, rem_id;
-  if (p.n_sub > 1 && 32 % p.n_sub == 0) {
-    rem_id = lid / p.n_sub;
-    sub = (lid + (lid >> 5)) % p.n_sub;
+  // Unit -> (sub-problem, tile, K segment).  Several sub-problems (the 9/6/6/4-tap parities of a stride-2 transposed conv) and / or cut
+  // tiles: tile-index-major, pattern-minor — every tile index owns pat_len units (sub-problem s contributes ks[s] of them) — and the
+  // order inside the pattern rotates every 32 workgroups: workgroups go to the 32 compute units of an XCD round-robin, all resident at
+  // once for these small launches, so with a fixed order unit j would get pattern entry j % pat_len every time (measured: the units
+  // holding only 9-tap workgroups finish at 190 us, the median at 100); rotating gives every unit the same mix.
+  int sub, rem_id, kseg = 0, kcut = 1, slot = -1;
+  if constexpr (FIXUP) {
+    if (p.pat_len > 0) {
+      rem_id = blockIdx.x / p.n_split_sub;
+      const int j = blockIdx.x - rem_id * p.n_split_sub;
+      sub = p.split_sub[j];
+      slot = rem_id * p.n_pat_split + p.first_slot[j];
+    } else {
+      sub = 0;
+      rem_id = p.nfull + blockIdx.x;
+      slot = blockIdx.x * p.ks[0];
+    }
+    kcut = p.ks[sub];
   } else {
-    sub = lid / per_sub;
-    rem_id = lid - sub * per_sub;
+    const int lid = xcd_remap(blockIdx.x, p.n_units);
+    if (p.pat_len > 0) {
+      const int L = p.pat_len;
+      rem_id = lid / L;
+      const int w = (32 % L == 0) ? (lid + (lid >> 5)) % L : lid - rem_id * L;
+      sub = p.pat_sub[w]; kseg = p.pat_k[w]; kcut = p.ks[sub];
+      slot = p.pat_slot[w] < 0 ? -1 : rem_id * p.n_pat_split + p.pat_slot[w];
+    } else {
+      sub = 0;
+      if (lid < p.nfull) rem_id = lid;
+      else {
+        const int v = lid - p.nfull;
+        kcut = p.ks[0];
+        rem_id = p.nfull + v / kcut;
+        kseg = v - (rem_id - p.nfull) * kcut;
+        slot = v;
+      }
+    }
   }
   const SubDesc& d = p.d[sub];
   const int nt = rem_id % p.n_tiles, mt = rem_id / p.n_tiles;
@@ -240,13 +279,31 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const int frag = (lane & 31) * LDT + (lane >> 5) * 4;
+  constexpr int WS_VEC = MI * NI * 4;                    // float4 pieces of a thread's accumulators; ws piece j of slot s, thread t at ((s * WS_VEC + j) * 256 + t)
+
+  if constexpr (FIXUP) {
+    for (int k = 0; k < kcut; ++k) {                     // fixed order: the result does not depend on which unit finished first
+      const f32x4* src = reinterpret_cast<const f32x4*>(p.ws) + ((int64_t)(slot + k) * WS_VEC) * 256 + tid;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = src[((mi * NI + ni) * 4 + q) * 256];
+            acc[mi][ni][4 * q] += v[0]; acc[mi][ni][4 * q + 1] += v[1]; acc[mi][ni][4 * q + 2] += v[2]; acc[mi][ni][4 * q + 3] += v[3];
+          }
+    }
+  } else {
+  // K range of this unit: K-tiles [it0, it1) of the tile's nk (balanced integer cut)
+  const int it0 = (int)((int64_t)nk * kseg / kcut), it1 = (int)((int64_t)nk * (kseg + 1) / kcut);
 
   // Register-staged double buffer: the global loads of tile it+1 are issued before the 64 MFMAs of tile it and written
   // to the other LDS buffer after them (one barrier per K-tile).  (Measured alternative: writing tile it+1 FIRST and
   // prefetching tile it+2 — one tile deeper — is 3-4 % slower here and 5 % faster in wgrad_f32_kernel, which uses it.)
-  int tap = 0, c0 = 0, buf = 0;
-  set_tap(0);
-  gload(0);
+  int tap = it0 / cchunks, c0 = (it0 - tap * cchunks) * BK, buf = 0;
+  set_tap(tap);
+  gload(c0);
   sstore(0);
   __syncthreads();
 
@@ -254,8 +311,8 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, acc_load = 0, acc_mfma = 0, acc_store = 0, acc_bar = 0, t_begin = 0;
   STAMP(t_begin);
 #endif
-  for (int it = 0; it < nk; ++it) {
-    const bool more = it + 1 < nk;
+  for (int it = it0; it < it1; ++it) {
+    const bool more = it + 1 < it1;
     STAMP(ts0);
     if (more) {
       c0 += BK;
@@ -314,13 +371,31 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   {
     unsigned long long t_end;
     STAMP(t_end);
-    const int slot = blockIdx.x == 0 ? 0 : (blockIdx.x == 7 ? 1 : (blockIdx.x == 300 ? 2 : (blockIdx.x == 700 ? 3 : (blockIdx.x == 1500 ? 4 : -1))));
-    if (slot >= 0 && tid == 0) {
-      tg_stamps[slot * 8 + 0] = acc_load; tg_stamps[slot * 8 + 1] = acc_mfma; tg_stamps[slot * 8 + 2] = acc_store;
-      tg_stamps[slot * 8 + 3] = acc_bar; tg_stamps[slot * 8 + 4] = t_end - t_begin; tg_stamps[slot * 8 + 5] = nk;
-      tg_stamps[slot * 8 + 6] = t_begin - t_entry;
+    const int sslot = blockIdx.x == 0 ? 0 : (blockIdx.x == 7 ? 1 : (blockIdx.x == 300 ? 2 : (blockIdx.x == 700 ? 3 : (blockIdx.x == 1500 ? 4 : -1))));
+    if (sslot >= 0 && tid == 0) {
+      tg_stamps[sslot * 8 + 0] = acc_load; tg_stamps[sslot * 8 + 1] = acc_mfma; tg_stamps[sslot * 8 + 2] = acc_store;
+      tg_stamps[sslot * 8 + 3] = acc_bar; tg_stamps[sslot * 8 + 4] = t_end - t_begin; tg_stamps[sslot * 8 + 5] = it1 - it0;
+      tg_stamps[sslot * 8 + 6] = t_begin - t_entry;
     }
   }
+#endif
+  if (slot >= 0) {
+    // a cut tile: this unit's accumulators go to the workspace as they lie in the registers (16 B per lane, 1 KB per wave-instruction) and
+    // the fix-up launch adds the tile's K segments up and runs the epilogue
+    f32x4* dst = reinterpret_cast<f32x4*>(p.ws) + ((int64_t)slot * WS_VEC) * 256 + tid;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+          dst[((mi * NI + ni) * 4 + q) * 256] = v;
+        }
+    return;
+  }
+  }  // !FIXUP
+#ifdef TG_STAMP
   unsigned long long t_epi0 = 0;
   STAMP(t_epi0);
 #endif
@@ -457,8 +532,8 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     unsigned long long t_epi1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(t_epi1);
-    const int slot = blockIdx.x == 0 ? 0 : (blockIdx.x == 7 ? 1 : (blockIdx.x == 300 ? 2 : (blockIdx.x == 700 ? 3 : (blockIdx.x == 1500 ? 4 : -1))));
-    if (slot >= 0 && tid == 0) tg_stamps[slot * 8 + 7] = t_epi1 - t_epi0;
+    const int sslot = blockIdx.x == 0 ? 0 : (blockIdx.x == 7 ? 1 : (blockIdx.x == 300 ? 2 : (blockIdx.x == 700 ? 3 : (blockIdx.x == 1500 ? 4 : -1))));
+    if (sslot >= 0 && tid == 0) tg_stamps[sslot * 8 + 7] = t_epi1 - t_epi0;
     if (tid == 0 && blockIdx.x < 8192) {
       tg_block_times[3 * blockIdx.x] = rt0;
       tg_block_times[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -748,9 +823,7 @@ int check_desc(const tg_igemm_desc* d) {
 
 template <int BM, int BN, int WM_, int WN_>
 static void launch_igemm(IgemmParams& p, hipStream_t s, bool bf16) {
-  p.m_tiles = (p.M + BM - 1) / BM;
-  p.n_tiles = (p.c_out + BN - 1) / BN;      // the last column tile may overhang: filter rows >= c_out read zeros / unused data, stores are masked by n_store
-  const dim3 grid(p.m_tiles * p.n_tiles * p.n_sub);
+  const dim3 grid(p.n_units);               // one workgroup per work unit (tg::igemm_schedule); the last column tile may overhang: filter rows >= c_out read zeros / unused data, stores are masked by n_store
   if (bf16) {
     if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, true>), grid, dim3(256), 0, s, p);
@@ -758,40 +831,55 @@ static void launch_igemm(IgemmParams& p, hipStream_t s, bool bf16) {
     if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, false>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, false>), grid, dim3(256), 0, s, p);
   }
+  if (p.n_fix > 0) {                        // tiles that were cut along K: add their partial sums up, then the usual epilogue (operand type plays no part)
+    if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, false, true>), dim3(p.n_fix), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, false, true>), dim3(p.n_fix), dim3(256), 0, s, p);
+  }
+}
+
+// the head / tail cut of a launch of the halo kernel's shape that does not fill whole rounds (conv3x3_bf16.hip): descriptors and segment
+// tables of the two parts.  Returns the head's image count, 0: no cut.
+struct HeadTail { tg_igemm_desc dh, dt; int32_t seg_h[8], seg_t[8]; int nh, nt, k0; };
+static int head_tail(const tg_igemm_desc* descs, int n_desc, const int32_t* seg_rows, int nseg, bool colsum, bool bf16, HeadTail* o) {
+  const int head = tg::conv3x3_bf16_split_images(descs, n_desc, seg_rows, colsum ? nseg : 0, bf16);
+  if (!head) return 0;
+  o->dh = descs[0]; o->dt = descs[0];
+  o->dh.n_img = head;
+  o->dt.n_img = descs[0].n_img - head;
+  const int64_t per_img = (int64_t)descs[0].h_in * descs[0].w_in;
+  o->nh = o->nt = o->k0 = 0;
+  if (colsum) {
+    int64_t left = (int64_t)head * per_img;                   // rows of the head still to hand out
+    for (int i = 0; i < nseg; ++i) {
+      const int64_t r = seg_rows[i], take = r < left ? r : left;
+      if (take > 0) o->seg_h[o->nh++] = (int32_t)take;
+      if (r - take > 0) {
+        if (o->nt == 0) o->k0 = i;
+        o->seg_t[o->nt++] = (int32_t)(r - take);
+      }
+      left -= take;
+    }
+  }
+  return head;
 }
 
 static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out, void* stream,
                       double* colsum, const int32_t* seg_rows, int nseg, bool bf16 = false, const float* ymul = nullptr, int ymul_act = 0,
-                      float ymul_alpha = 0.f) {
+                      float ymul_alpha = 0.f, void* scratch = nullptr, int64_t scratch_bytes = 0) {
   TG_REQUIRE(descs && n_desc >= 1 && n_desc <= MAX_SUB, "igemm: n_desc=%d out of range", n_desc);
   TG_REQUIRE(in && w && out, "igemm: null buffer");
   // A 3x3 layer of the halo kernel's shape whose launch does not fill whole rounds of one workgroup per CU (conv3x3_bf16.hip): the leading
   // images that do go to that kernel, the few left over to the generic one — two launches over disjoint image ranges of the same buffers
   // (the column sums of both accumulate into the same per-segment accumulators).
-  if (const int head = tg::conv3x3_bf16_split_images(descs, n_desc, seg_rows, colsum ? nseg : 0, bf16)) {
-    tg_igemm_desc dh = descs[0], dt = descs[0];
-    dh.n_img = head;
-    dt.n_img = descs[0].n_img - head;
+  HeadTail ht;
+  if (const int head = head_tail(descs, n_desc, seg_rows, nseg, colsum != nullptr, bf16, &ht)) {
     const int64_t per_img = (int64_t)descs[0].h_in * descs[0].w_in;
-    int32_t seg_h[8], seg_t[8];
-    int nh = 0, nt = 0, k0 = 0;
-    if (colsum) {
-      int64_t left = (int64_t)head * per_img;                   // rows of the head still to hand out
-      for (int i = 0; i < nseg; ++i) {
-        const int64_t r = seg_rows[i], take = r < left ? r : left;
-        if (take > 0) seg_h[nh++] = (int32_t)take;
-        if (r - take > 0) {
-          if (nt == 0) k0 = i;
-          seg_t[nt++] = (int32_t)(r - take);
-        }
-        left -= take;
-      }
-    }
-    int rc = igemm_impl(&dh, 1, in, w, bias, out, stream, colsum, colsum ? seg_h : nullptr, nh, bf16, ymul, ymul_act, ymul_alpha);
+    int rc = igemm_impl(&ht.dh, 1, in, w, bias, out, stream, colsum, colsum ? ht.seg_h : nullptr, ht.nh, bf16, ymul, ymul_act, ymul_alpha, scratch, scratch_bytes);
     if (rc != TG_OK) return rc;
     const int64_t o_in = (int64_t)head * per_img * descs[0].ld_in, o_out = (int64_t)head * per_img * descs[0].ld_out;
-    return igemm_impl(&dt, 1, in + o_in, w, bias, out + o_out, stream, colsum ? colsum + (int64_t)k0 * descs[0].c_out : nullptr, colsum ? seg_t : nullptr, nt, bf16,
-                      ymul ? ymul + o_out : nullptr, ymul_act, ymul_alpha);
+    // (the tail is stream-ordered behind the head: both may use the same scratch)
+    return igemm_impl(&ht.dt, 1, in + o_in, w, bias, out + o_out, stream, colsum ? colsum + (int64_t)ht.k0 * descs[0].c_out : nullptr, colsum ? ht.seg_t : nullptr,
+                      ht.nt, bf16, ymul ? ymul + o_out : nullptr, ymul_act, ymul_alpha, scratch, scratch_bytes);
   }
   IgemmParams p;
   p.in = in; p.w = w; p.bias = bias; p.out = out; p.n_sub = n_desc;
@@ -802,9 +890,7 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
   // sub-problems longest first: workgroups are dispatched in index order, so the 9-tap parity of a 5x5 s2 transposed
   // conv starts before the 4-tap one instead of forming the tail
   int order[MAX_SUB] = {0, 1, 2, 3};
-  for (int i = 0; i < n_desc; ++i)
-    for (int j = i + 1; j < n_desc; ++j)
-      if (descs[order[j]].n_taps > descs[order[i]].n_taps) { int t_ = order[i]; order[i] = order[j]; order[j] = t_; }
+  tg::igemm_sub_order(descs, n_desc, order);
   for (int i = 0; i < n_desc; ++i) {
     int rc = check_desc(&descs[order[i]]);
     if (rc != TG_OK) return rc;
@@ -843,17 +929,38 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
   for (int i = 0; i < n_desc; ++i) taps += descs[i].n_taps;
   const double flops = 2.0 * p.M * d->c_out * taps * d->ld_in;
   const double bytes = 4.0 * ((double)p.M * d->ld_in + (double)p.M * d->n_store * n_desc + (double)d->c_out * taps * d->ld_in);
-  char desc[96];
-  snprintf(desc, sizeof(desc), "M=%dx%d N=%d K=%gx%d in=%dx%d s=%d os=%d%s", n_desc, p.M, d->c_out, taps, d->ld_in, d->h_in, d->w_in, d->s_y, d->os_y,
-           bf16 ? " bf16" : "");
   hipStream_t s = tg::as_stream(stream);
-  tg::ProfScope prof(tg::PC_IGEMM, flops, bytes, s, desc);
-  if (tg::conv3x3_bf16_applicable(descs, n_desc, seg_rows, colsum ? nseg : 0, bf16))      // the classifier's 3x3 layers: halo-tiled kernel (both operand types)
-    return tg::conv3x3_bf16_launch(d, in, w, bias, out, colsum, seg_rows, nseg, ymul, ymul_act, ymul_alpha, p.in_bytes, p.w_bytes, p.out_bytes, s, bf16);
+  const bool halo = tg::conv3x3_bf16_applicable(descs, n_desc, seg_rows, colsum ? nseg : 0, bf16);      // the classifier's 3x3 layers: halo-tiled kernel (both operand types)
   // tile choice by the quantisation cost model of geom.cpp (tg::igemm_pick_tile; also behind tg_igemm_tile / tg_igemm_colsum_supported)
   int bm = 0, bn = 0;
-  TG_REQUIRE(tg::igemm_pick_tile(descs, n_desc, colsum != nullptr, seg_rows, nseg, bf16, &bm, &bn), "igemm: no tile fits c_out=%d with the given segments",
-             d->c_out);
+  tg::IgemmSched sc;
+  std::memset(&sc, 0, sizeof sc);
+  if (!halo) {
+    TG_REQUIRE(tg::igemm_pick_tile(descs, n_desc, colsum != nullptr, seg_rows, nseg, bf16, &bm, &bn), "igemm: no tile fits c_out=%d with the given segments",
+               d->c_out);
+    // work units: tiles of the last partial round / of an under-filled launch / of the long sub-problems are cut along K when the caller
+    // brought scratch for their partial sums (tg_igemm_workspace_bytes); otherwise one unit per tile
+    p.m_tiles = (p.M + bm - 1) / bm;
+    p.n_tiles = (p.c_out + bn - 1) / bn;
+    int nk[MAX_SUB] = {0, 0, 0, 0};
+    for (int i = 0; i < n_desc; ++i) nk[i] = descs[order[i]].n_taps * (d->ld_in / BK);
+    static const int dbg_mask = getenv("TG_IGEMM_SPLIT_MASK") ? atoi(getenv("TG_IGEMM_SPLIT_MASK")) : 7;      // debugging aid, read once: 1 plain, 2 column-sum variants, 4 several sub-problems
+    const int kind = n_desc > 1 ? 4 : (colsum ? 2 : 1);
+    tg::igemm_schedule(n_desc, nk, (int64_t)p.m_tiles * p.n_tiles, bm, bn, 2 * tg::halo_compute_units(), scratch != nullptr && (dbg_mask & kind), &sc);
+    if (sc.ws_bytes > scratch_bytes || (reinterpret_cast<uintptr_t>(scratch) & 15))      // less scratch than the cut needs: the one-launch schedule
+      tg::igemm_schedule(n_desc, nk, (int64_t)p.m_tiles * p.n_tiles, bm, bn, 2 * tg::halo_compute_units(), false, &sc);
+  }
+  char desc[128];
+  snprintf(desc, sizeof(desc), "M=%dx%d N=%d K=%gx%d in=%dx%d s=%d os=%d%s tile=%dx%d units=%d fix=%d ks=%d/%d/%d/%d", n_desc, p.M, d->c_out, taps, d->ld_in, d->h_in,
+           d->w_in, d->s_y, d->os_y, bf16 ? " bf16" : "", bm, bn, sc.n_units, sc.n_fix, sc.ks[0], sc.ks[1], sc.ks[2], sc.ks[3]);
+  tg::ProfScope prof(tg::PC_IGEMM, flops, bytes, s, desc);
+  if (halo)
+    return tg::conv3x3_bf16_launch(d, in, w, bias, out, colsum, seg_rows, nseg, ymul, ymul_act, ymul_alpha, p.in_bytes, p.w_bytes, p.out_bytes, s, bf16,
+                                   scratch, scratch_bytes);
+  p.n_units = sc.n_units; p.n_fix = sc.n_fix; p.nfull = sc.nfull; p.pat_len = sc.pat_len; p.n_pat_split = sc.n_pat_split; p.n_split_sub = sc.n_split_sub;
+  for (int i = 0; i < MAX_SUB; ++i) { p.ks[i] = sc.ks[i]; p.split_sub[i] = sc.split_sub[i]; p.first_slot[i] = sc.first_slot[i]; }
+  for (int i = 0; i < 16; ++i) { p.pat_sub[i] = sc.pat_sub[i]; p.pat_k[i] = sc.pat_k[i]; p.pat_slot[i] = sc.pat_slot[i]; }
+  p.ws = static_cast<float*>(scratch);
   if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2>(p, s, bf16);
   else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2>(p, s, bf16);
   else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2>(p, s, bf16);
@@ -877,17 +984,48 @@ extern "C" int tg_debug_read_stamps(unsigned long long* out) {
 #endif
 
 extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,
-                                  void* stream) {
-  return igemm_impl(descs, n_desc, in, w, bias, out, stream, nullptr, nullptr, 0);
+                                  void* scratch, int64_t scratch_bytes, void* stream) {
+  return igemm_impl(descs, n_desc, in, w, bias, out, stream, nullptr, nullptr, 0, false, nullptr, 0, 0.f, scratch, scratch_bytes);
 }
 
-extern "C" int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* stream) {
-  return igemm_impl(d, 1, in, w, bias, out, stream, nullptr, nullptr, 0);
+extern "C" int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* scratch,
+                            int64_t scratch_bytes, void* stream) {
+  return igemm_impl(d, 1, in, w, bias, out, stream, nullptr, nullptr, 0, false, nullptr, 0, 0.f, scratch, scratch_bytes);
+}
+
+// scratch a launch of these descriptors can use: the larger of the halo kernel's packed bf16 filter (REQUIRED by such a launch) and the
+// partial sums of the tiles the generic kernel's schedule cuts along K (optional: with less the launch runs as one unit per tile);
+// a launch that is cut into a halo head and a generic tail uses the scratch for one after the other.  Mirrors the routing of igemm_impl.
+static int64_t igemm_ws_bytes(const tg_igemm_desc* descs, int n_desc, const int32_t* seg_rows, int nseg, bool bf16) {
+  const bool colsum = nseg > 0;
+  HeadTail ht;
+  if (head_tail(descs, n_desc, seg_rows, nseg, colsum, bf16, &ht)) {
+    const int64_t a = igemm_ws_bytes(&ht.dh, 1, colsum ? ht.seg_h : nullptr, ht.nh, bf16);
+    const int64_t b = igemm_ws_bytes(&ht.dt, 1, colsum ? ht.seg_t : nullptr, ht.nt, bf16);
+    return a > b ? a : b;
+  }
+  if (tg::conv3x3_bf16_applicable(descs, n_desc, seg_rows, colsum ? nseg : 0, bf16)) return bf16 ? tg::conv3x3_bf16_pack_bytes(descs, n_desc) : 0;
+  int bm = 0, bn = 0;
+  if (!tg::igemm_pick_tile(descs, n_desc, colsum, seg_rows, nseg, bf16, &bm, &bn)) return 0;
+  int order[MAX_SUB] = {0, 1, 2, 3}, nk[MAX_SUB] = {0, 0, 0, 0};
+  tg::igemm_sub_order(descs, n_desc, order);
+  for (int i = 0; i < n_desc; ++i) nk[i] = descs[order[i]].n_taps * (descs[0].ld_in / BK);
+  const int64_t M = (int64_t)descs[0].n_img * descs[0].h_v * descs[0].w_v;
+  tg::IgemmSched sc;
+  tg::igemm_schedule(n_desc, nk, ((M + bm - 1) / bm) * ((descs[0].c_out + bn - 1) / bn), bm, bn, 2 * tg::halo_compute_units(), true, &sc);
+  return sc.ws_bytes;
+}
+
+extern "C" int64_t tg_igemm_workspace_bytes(const tg_igemm_desc* descs, int n_desc, const int32_t* seg_rows, int nseg, int bf16) {
+  if (!descs || n_desc < 1 || n_desc > MAX_SUB || nseg < 0 || nseg > 8 || (nseg > 0 && !seg_rows)) { tg::set_error("igemm_workspace_bytes: bad arguments"); return TG_ERR_INVALID; }
+  for (int i = 0; i < n_desc; ++i)
+    if (descs[i].ld_in <= 0 || descs[i].c_out <= 0 || descs[i].n_taps <= 0 || descs[i].n_taps > TG_MAX_TAPS || descs[i].n_img <= 0) { tg::set_error("igemm_workspace_bytes: bad descriptor"); return TG_ERR_INVALID; }
+  return igemm_ws_bytes(descs, n_desc, seg_rows, nseg, bf16 != 0);
 }
 
 static int igemm_colsum_impl(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
                              double* colsum, int colsum_zeroed, void* stream, bool bf16, const float* ymul = nullptr, int ymul_act = 0,
-                             float ymul_alpha = 0.f) {
+                             float ymul_alpha = 0.f, void* scratch = nullptr, int64_t scratch_bytes = 0) {
   TG_REQUIRE(d && colsum && seg_rows && nseg >= 1 && nseg <= 8, "igemm_colsum: bad args");
   TG_REQUIRE(d->n_group == 0, "igemm_colsum: grouped columns are not supported");
   TG_REQUIRE(d->act == TG_ACT_NONE, "igemm_colsum: the statistics are of the raw convolution output (no activation)");
@@ -898,38 +1036,41 @@ static int igemm_colsum_impl(const tg_igemm_desc* d, const float* in, const floa
     hipError_t e = hipMemsetAsync(colsum, 0, sizeof(double) * nseg * d->c_out, tg::as_stream(stream));
     if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(colsum)");
   }
-  return igemm_impl(d, 1, in, w, nullptr, out, stream, colsum, seg_rows, nseg, bf16, ymul, ymul_act, ymul_alpha);
+  return igemm_impl(d, 1, in, w, nullptr, out, stream, colsum, seg_rows, nseg, bf16, ymul, ymul_act, ymul_alpha, scratch, scratch_bytes);
 }
 
 extern "C" int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
-                                   double* colsum, int colsum_zeroed, void* stream) {
-  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, false);
+                                   double* colsum, int colsum_zeroed, void* scratch, int64_t scratch_bytes, void* stream) {
+  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, false, nullptr, 0, 0.f, scratch, scratch_bytes);
 }
 
 extern "C" int tg_igemm_colsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
-                                    double* colsum, int colsum_zeroed, void* stream) {
-  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, true);
+                                    double* colsum, int colsum_zeroed, void* scratch, int64_t scratch_bytes, void* stream) {
+  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, true, nullptr, 0, 0.f, scratch, scratch_bytes);
 }
 
 extern "C" int tg_igemm_actsum_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* yact, int act, float alpha, float* out,
-                                   const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* stream) {
+                                   const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* scratch, int64_t scratch_bytes,
+                                   void* stream) {
   TG_REQUIRE(yact != nullptr, "igemm_actsum: yact is NULL");
-  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, false, yact, act, alpha);
+  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, false, yact, act, alpha, scratch, scratch_bytes);
 }
 
 extern "C" int tg_igemm_actsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* yact, int act, float alpha, float* out,
-                                    const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* stream) {
+                                    const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* scratch, int64_t scratch_bytes,
+                                    void* stream) {
   TG_REQUIRE(yact != nullptr, "igemm_actsum: yact is NULL");
-  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, true, yact, act, alpha);
+  return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, true, yact, act, alpha, scratch, scratch_bytes);
 }
 
 extern "C" int tg_igemm_multi_bf16(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,
-                                   void* stream) {
-  return igemm_impl(descs, n_desc, in, w, bias, out, stream, nullptr, nullptr, 0, true);
+                                   void* scratch, int64_t scratch_bytes, void* stream) {
+  return igemm_impl(descs, n_desc, in, w, bias, out, stream, nullptr, nullptr, 0, true, nullptr, 0, 0.f, scratch, scratch_bytes);
 }
 
-extern "C" int tg_igemm_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* stream) {
-  return igemm_impl(d, 1, in, w, bias, out, stream, nullptr, nullptr, 0, true);
+extern "C" int tg_igemm_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* scratch,
+                             int64_t scratch_bytes, void* stream) {
+  return igemm_impl(d, 1, in, w, bias, out, stream, nullptr, nullptr, 0, true, nullptr, 0, 0.f, scratch, scratch_bytes);
 }
 
 template <int CT, int NT, int WC, int WN, int WK>

@@ -23,7 +23,7 @@ int hip_fail(hipError_t e, const char* what) {
 
 static const char* kClassNames[PC_COUNT] = {"igemm_f32", "wgrad_f32", "prep", "norm", "elementwise", "loss", "optim"};
 
-struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; char desc[96]; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; char desc[160]; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;

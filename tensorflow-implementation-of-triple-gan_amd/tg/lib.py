@@ -58,7 +58,8 @@ _SCALARS = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint32_
 _RET = {"int": C.c_int, "int64_t": C.c_int64, "const char*": C.c_char_p}
 _NOCHECK = {"tg_version", "tg_last_error_string", "tg_device_count", "tg_prof_num_classes", "tg_prof_class_name",
             "tg_colstats_workspace_floats", "tg_igemm_colsum_supported", "tg_conv3x3_policy", "tg_conv3x3_launches"}
-_NEGATIVE_IS_ERROR = {"tg_wgrad_splits", "tg_wgrad_splits_bf16", "tg_wgrad_workspace_bytes", "tg_filter_workspace_bytes"}     # return a count / size, < 0 on error
+_NEGATIVE_IS_ERROR = {"tg_wgrad_splits", "tg_wgrad_splits_bf16", "tg_wgrad_workspace_bytes", "tg_filter_workspace_bytes",
+                      "tg_igemm_workspace_bytes"}     # return a count / size, < 0 on error
 HOST_INT_ARRAYS = {"seg_rows", "tapmap"}          # pointer arguments that are HOST arrays
 
 
@@ -140,6 +141,29 @@ def call(name, *args):
     if rc != 0:
         raise TgError("%s failed (%d): %s" % (name, rc, lib.tg_last_error_string().decode()))
     return rc
+
+
+def igemm_workspace_bytes(name, args):
+    """tg_igemm_workspace_bytes for a call `name(*args)` of a tg_igemm_* entry point written WITHOUT its (scratch, scratch_bytes)
+    arguments: descriptors, segments and operand type are read off the argument list."""
+    n_desc = args[1] if '_multi_' in name else 1
+    d0 = C.byref(args[0]) if isinstance(args[0], IgemmDesc) else args[0]
+    seg, nseg = None, 0
+    if '_colsum_' in name:
+        seg, nseg = args[4], args[5]
+    elif '_actsum_' in name:
+        seg, nseg = args[7], args[8]
+    return call('tg_igemm_workspace_bytes', d0, n_desc, seg, nseg, 1 if name.endswith('bf16') else 0)
+
+
+def call_igemm(name, *args, scratch=True):
+    """call a tg_igemm_* entry point with the arguments of include/tg_kernels.h minus (scratch, scratch_bytes): a torch buffer of the size
+    the library asks for is allocated and handed in (tools and tests; the package's own launches use per-call-site workspaces, tg/ops.py).
+    scratch=False: NULL scratch (the one-launch schedule; an error for a bf16 launch of the halo kernel)."""
+    import torch
+    need = igemm_workspace_bytes(name, args) if scratch else 0
+    buf = torch.empty(max(need // 4, 4), dtype=torch.float32, device='cuda') if need > 0 else None
+    return call(name, *(args[:-1] + (ptr(buf), need, args[-1])))
 
 
 def ptr(t):

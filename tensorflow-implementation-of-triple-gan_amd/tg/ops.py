@@ -14,11 +14,25 @@ _MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_ig
 
 
 def _call(name, *args):
-    """lib.call; the four MFMA launches switch to their bf16-operand variants when the context asks for the
-    "bf16 MFMA conv path" (Context.mfma_dtype = 'bf16', BASELINE.json configs[3])."""
-    if name in _MFMA_F32 and ctx().mfma_dtype == 'bf16':
-        name = name[:-3] + 'bf16'
+    """lib.call; the MFMA launches switch to their bf16-operand variants when the context asks for the "bf16 MFMA conv path"
+    (Context.mfma_dtype = 'bf16', BASELINE.json configs[3]).  The igemm entry points take caller-owned scratch (include/tg_kernels.h):
+    sized by tg_igemm_workspace_bytes — the partial sums of tiles the schedule cuts along K, the packed bf16 filter of the 3x3 kernel —
+    one buffer per call site like every other workspace; callers here pass the arguments WITHOUT it."""
+    cx = ctx()
+    if name in _MFMA_F32:
+        bf16 = cx.mfma_dtype == 'bf16'
+        if bf16:
+            name = name[:-3] + 'bf16'
+        if not name.startswith('tg_wgrad'):
+            args = igemm_scratch(cx, name, args, bf16)
     return lib.call(name, *args)
+
+
+def igemm_scratch(cx, name, args, bf16):
+    """insert (scratch, scratch_bytes) in front of the stream argument of a tg_igemm_* call."""
+    need = lib.igemm_workspace_bytes(name, args)
+    buf = cx.scratch('igws', (need + 3) // 4) if need > 0 else None
+    return args[:-1] + (_p(buf), need, args[-1])
 
 
 def _p(t):

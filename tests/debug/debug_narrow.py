@@ -18,7 +18,7 @@ bp = np.zeros(co_p, np.float32); bp[:cout] = bias
 xd, wd, bd = torch.from_numpy(xp).cuda(), torch.from_numpy(w_pad).cuda(), torch.from_numpy(bp).cuda()
 yd = torch.full((n, 2 * h, 2 * w, cout), 7.0, device='cuda')
 for d in geom.deconv_fwd(n, h, w, ci_p, co_p, ld_out=cout, n_store=cout, act=None):
-    lib.call("tg_igemm_f32", d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
+    lib.call("tg_igemm_f32", d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), None, 0, lib.cur_stream())
 y = yd.cpu().numpy()
 e = np.abs(y - pre)
 print('max err', e.max(), 'unwritten', (y == 7.0).sum())

@@ -13,15 +13,16 @@ Two fixtures (FIXTURES):
   * 'hard'  — pixel noise raised until the curve does NOT saturate (plateau error between 5 % and 30 %), the last 100 iterations at
               2.5x the batch sizes: +-0.3 pp is checked where a classifier that merely "works" does not pass.
 
-Three variants per fixture (VARIANTS) — the SAME run evaluated three ways:
-  * 'f64'   — float64 (the golden trajectory),
-  * 'f32a'  — float32, NumPy / BLAS summation order as it comes,
-  * 'f32b'  — float32, every contraction summed BACKWARDS (oracle.tf_ops.SUM_REVERSED) and the im2col chunks 8x smaller (another
-              partition of the filter-gradient sums).
-f32a and f32b are two correct float32 evaluations of the reference's arithmetic that differ only in rounding.  Their distance from
-f64 and from each other is what a correct float32 implementation can be expected to show on this trajectory; the HIP path is
-required to stay inside the envelope of the three (+-0.3 pp) — tests/test_gpu_long_horizon.py — and no bound in that test is set by
-hand or taken from the HIP path's own behaviour.
+Variants per fixture (VARIANTS) — the SAME run evaluated several ways:
+  * 'f64'          — float64 (the golden trajectory),
+  * 'f32a' ... 'f32f' — float32 with the reduction order of every conv / dense contraction and of the filter-gradient sums varied: as
+                     NumPy / BLAS has it or BACKWARDS (oracle.tf_ops.SUM_REVERSED), the im2col batch chunks as they are, 3x or 8x smaller
+                     (another partition of the filter-gradient accumulation).
+The float32 variants are correct float32 evaluations of the reference's arithmetic that differ ONLY in rounding.  Their distance from f64
+and from each other is what a correct float32 implementation can be expected to show on this free-running trajectory (it is large while
+the error falls: the run is chaotic there — at iteration 50 of 'k300' they sit at 65 % and 27 % against float64's 6 %); the HIP path is
+required to stay inside the envelope of the committed variants (tests/test_gpu_long_horizon.py), and no bound in that test is set by hand
+or taken from the HIP path's own behaviour.  Not every variant needs to exist for every fixture: load() returns those that are committed.
 
 tests/test_golden.py re-checks the first iterations of every committed file against the oracle on the CPU.
 
@@ -57,6 +58,10 @@ VARIANTS = {
     'f64': dict(dtype=np.float64, reversed=False, chunk=1),
     'f32a': dict(dtype=np.float32, reversed=False, chunk=1),
     'f32b': dict(dtype=np.float32, reversed=True, chunk=8),
+    'f32c': dict(dtype=np.float32, reversed=True, chunk=1),
+    'f32d': dict(dtype=np.float32, reversed=False, chunk=8),
+    'f32e': dict(dtype=np.float32, reversed=False, chunk=3),
+    'f32f': dict(dtype=np.float32, reversed=True, chunk=3),
 }
 K = 300                 # every fixture's length
 
@@ -141,8 +146,10 @@ def run(fixture='k300', variant='f64', k_steps=None, log=None, n_test=N_TEST, ev
 
 
 def load(fixture):
-    """{variant: npz} of the committed files of one fixture."""
-    return {v: np.load(path(fixture, v)) for v in VARIANTS}
+    """{variant: npz} of the committed files of one fixture ('f64' must be among them)."""
+    out = {v: np.load(path(fixture, v)) for v in VARIANTS if os.path.exists(path(fixture, v))}
+    assert 'f64' in out, 'the float64 trajectory of %r is missing' % fixture
+    return out
 
 
 if __name__ == "__main__":

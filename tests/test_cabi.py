@@ -97,6 +97,30 @@ def test_product_never_imports_the_oracle():
                 assert not pat.search(open(os.path.join(dirpath, f)).read()), os.path.join(dirpath, f)
 
 
+def test_library_never_allocates_device_memory():
+    """SURVEY §8b / include/tg_kernels.h: the caller owns every buffer — scratch is sized by a query (tg_*_workspace_bytes) and handed
+    in.  No allocation call may appear in the kernel library's sources, and the bf16 3x3 path's scratch query is exported and answers
+    on the host (no GPU needed): the packed filter of a 256 -> 256 layer is 2 x 4 x 9 images of 16 KB, a layer of another shape needs none."""
+    csrc = os.path.join(ROOT, "tensorflow-implementation-of-triple-gan_amd", "csrc")
+    pat = re.compile(r"\bhip(Malloc|MallocAsync|MallocManaged|HostMalloc|Free|FreeAsync|ExtMallocWithFlags)\b")
+    for dirpath, _, files in os.walk(csrc):
+        for f in files:
+            if f.endswith((".hip", ".cpp", ".h")):
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), os.path.join(dirpath, f)
+    from tg import geom, lib
+    d = geom.conv_fwd(250, 16, 16, 256, 256, 3, 1, 'SAME')            # 500 tiles: two rounds of the halo kernel
+    assert lib.call('tg_igemm_workspace_bytes', C.byref(d), 1, None, 0, 1) == 2 * 4 * 9 * 16384
+    assert lib.call('tg_igemm_workspace_bytes', C.byref(d), 1, None, 0, 0) == 0              # exact-fp32 operands: no packed filter
+    # generic kernel: 1 000 tiles of 64 x 64 fill two rounds of 512 slots -> nothing is cut; 225 tiles (the generator's first input gradient)
+    # are cut in two and their partial sums need 450 x 64 x 64 floats
+    assert lib.call('tg_igemm_workspace_bytes', C.byref(geom.conv_fwd(250, 16, 16, 64, 64, 3, 1, 'SAME')), 1, None, 0, 0) == 0
+    dg = geom.deconv_dgrad(100, 4, 4, 544, 256)
+    assert lib.call('tg_igemm_workspace_bytes', C.byref(dg), 1, None, 0, 0) == 450 * 64 * 64 * 4
+    bad = lib.IgemmDesc()
+    with pytest.raises(lib.TgError, match='bad descriptor'):
+        lib.call('tg_igemm_workspace_bytes', C.byref(bad), 1, None, 0, 0)
+
+
 def test_comm_library_exports_every_declared_symbol():
     """include/tg_comm.h <-> libtg_comm.so (no collective is issued: loading needs RCCL in the process, not a GPU)."""
     from tg import comm, lib

@@ -38,20 +38,30 @@ def test_goodgan_oracle_reproduces_the_golden_prefix():
 
 
 def test_oracle_reproduces_the_long_horizon_prefix():
-    """tests/golden/cifar10_long_k300.npz (make_golden_long.py: 300 free-running iterations, error rate on 1 000 images every 25) —
-    the first iteration and the initial error rate are recomputed here; the file's own invariants are checked."""
+    """tests/golden/cifar10_long_<fixture>_<variant>.npz (make_golden_long.py: 300 free-running iterations, error rate on 1 000 images at
+    the fixture's checkpoints, float64 + float32 controls) — the first iteration of every fixture is recomputed here (float64 to 1e-9; the
+    float32 controls to float32 accuracy: BLAS kernels differ between hosts); the files' own invariants are checked."""
     import make_golden_long as M
     from oracle import step_cifar10 as S
-    g = np.load(M.path(M.K))
-    assert g['losses'].shape == (M.K, 3) and np.isfinite(g['losses']).all()
-    assert list(g['eval_steps']) == [0] + list(range(M.EVAL_EVERY, M.K + 1, M.EVAL_EVERY)) and g['logits_final'].shape == (M.N_TEST, 10)
-    assert g['eval_acc'][-1] >= 0.99 and g['eval_acc'][0] <= 0.3               # the task is learnt within the run
-    st = S.new_state(M.f64(S.init_params(0)))
-    zca = tuple(np.asarray(a, np.float64) for a in S.synth_zca())
-    b, r = M.inputs(0)
-    np.testing.assert_allclose(S.train_step(st, M.f64(b), M.f64(r), M.HYPER, zca), g['losses'][0], rtol=1e-9, atol=1e-12)
-    x, y, noise = M.test_split()
-    P0 = M.f64(S.init_params(0))
-    from oracle import nets_cifar10 as N
-    lg, _, _ = N.classifier_fwd(P0, N.zca_apply(x[:100].astype(np.float64), *zca), False, {'noise': noise[:100].astype(np.float64)})
-    assert lg.shape == (100, 10)
+    for fixture in M.FIXTURES:
+        ctl = M.load(fixture)
+        assert len(ctl) >= 3, (fixture, sorted(ctl))                      # float64 and at least two float32 controls
+        K = M.total_steps(fixture)
+        want_steps = sorted(set([0, K] + list(M.FIXTURES[fixture]['evals'])))
+        for name, g in ctl.items():
+            assert g['losses'].shape == (K, 3) and np.isfinite(g['losses']).all(), (fixture, name)
+            assert [int(s) for s in g['eval_steps']] == want_steps and g['logits_final'].shape == (M.N_TEST, 10), (fixture, name)
+            assert g['eval_acc'][0] <= 0.3                                    # starts at chance level
+        err = {n: 1.0 - g['eval_acc'] for n, g in ctl.items()}
+        if fixture == 'k300':
+            assert all(e[-1] == 0.0 for e in err.values())                    # the saturating task: learnt by every variant
+            assert max(e[10] for e in err.values()) - min(e[10] for e in err.values()) > 0.1     # ... along visibly different trajectories (iteration 50)
+        else:
+            assert all(0.03 <= e[-1] <= 0.45 for e in err.values()), {n: float(e[-1]) for n, e in err.items()}      # a plateau that is not 0
+        zca = tuple(np.asarray(a, np.float64) for a in S.synth_zca())
+        b, r = M.inputs(0, fixture)
+        st = S.new_state(M.f64(S.init_params(0)))
+        l64 = S.train_step(st, M.f64(b), M.f64(r), M.HYPER, zca)
+        np.testing.assert_allclose(l64, ctl['f64']['losses'][0], rtol=1e-9, atol=1e-12)
+        for name, g in ctl.items():
+            np.testing.assert_allclose(g['losses'][0], l64, rtol=2e-3, atol=2e-3)         # one iteration: float32 rounding only

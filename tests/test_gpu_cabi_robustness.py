@@ -72,3 +72,36 @@ def test_every_entry_point_survives_empty_inputs(tmp_path):
     assert not bad, bad                                                  # -2 = a HIP call failed (e.g. an empty grid was launched)
     no_msg = [k for k, v in rcs.items() if v[0] == -1 and not v[1]]
     assert not no_msg, no_msg                                            # every rejection explains itself
+
+
+def test_bf16_launch_without_its_scratch_is_an_error_not_another_kernel():
+    """include/tg_kernels.h: the bf16 3x3 kernel packs its filter into CALLER-OWNED scratch (size: tg_igemm_workspace_bytes).  A
+    launch that needs it and gets none / too little fails with a message naming the size — round 2 silently took a slower kernel (and
+    allocated device memory inside the library)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tensorflow-implementation-of-triple-gan_amd"))
+    import torch
+    from tg import geom, lib
+    lib.load()
+    n, hw, ci, co = 16, 16, 128, 128
+    d = geom.conv_fwd(n, hw, hw, ci, co, 3, 1, 'SAME')
+    x = torch.randn(n, hw, hw, ci, device='cuda')
+    w = torch.randn(co, 9, ci, device='cuda') * 0.05
+    y = torch.zeros(n, hw, hw, co, device='cuda')
+    st = lib.cur_stream()
+    was = lib.call('tg_conv3x3_policy', 1)                    # "wherever the layer applies": this small launch takes the halo kernel
+    try:
+        need = lib.call('tg_igemm_workspace_bytes', C.byref(d), 1, None, 0, 1)
+        assert need == 1 * 2 * 9 * 16384
+        before = lib.call('tg_conv3x3_launches')
+        for scratch, nbytes in ((None, 0), (torch.empty(need // 4, device='cuda'), need - 16)):
+            with pytest.raises(lib.TgError, match='bytes of scratch'):
+                lib.call('tg_igemm_bf16', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), lib.ptr(scratch), nbytes, st)
+        torch.cuda.synchronize()
+        assert float(y.abs().max()) == 0.0 and lib.call('tg_conv3x3_launches') == before          # nothing ran
+        wpk = torch.empty(need // 4, device='cuda')
+        lib.call('tg_igemm_bf16', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), lib.ptr(wpk), need, st)
+        torch.cuda.synchronize()
+        assert lib.call('tg_conv3x3_launches') == before + 1 and float(y.abs().max()) > 0.0
+    finally:
+        lib.call('tg_conv3x3_policy', was)

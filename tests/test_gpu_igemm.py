@@ -96,7 +96,7 @@ def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad, prec):
     yd = torch.full((n, ho, wo, co_p), 7.0, device='cuda')
     d = geom.conv_fwd(n, h, w, ci_p, co_p, k, s, pad, act='lrelu')
     halo0 = lib.call('tg_conv3x3_launches')
-    lib.call("tg_igemm_" + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
+    lib.call_igemm("tg_igemm_" + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
     assert lib.call('tg_conv3x3_launches') - halo0 == int(_takes_halo_kernel(prec, h, w, ci_p, co_p, k, s, pad))
     y = yd.cpu().numpy()
     close(y[..., :cout], y_ref, scale)
@@ -113,7 +113,7 @@ def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad, prec):
     assert len(descs) == s * s
     halo0 = lib.call('tg_conv3x3_launches')
     for dd in descs:
-        lib.call("tg_igemm_" + prec, dd, lib.ptr(dyd), lib.ptr(whd), None, lib.ptr(dxd), lib.cur_stream())
+        lib.call_igemm("tg_igemm_" + prec, dd, lib.ptr(dyd), lib.ptr(whd), None, lib.ptr(dxd), lib.cur_stream())
     assert lib.call('tg_conv3x3_launches') - halo0 == int(_takes_halo_kernel(prec, h, w, co_p, ci_p, k, s, pad))
     dx = dxd.cpu().numpy()
     close(dx[..., :cin], dx_ref, np.abs(dy).max() * np.abs(wt).max() * k * k * cout)
@@ -153,7 +153,7 @@ def test_deconv5x5s2_fwd_dgrad_wgrad(n, h, w, cin, cout, prec):
     # store only the logical channels (ld_out = cout) — the generator's last layer writes [N,32,32,3]
     yd = torch.full((n, 2 * h, 2 * w, cout), 7.0, device='cuda')
     for d in geom.deconv_fwd(n, h, w, ci_p, co_p, ld_out=cout, n_store=cout, act='tanh'):
-        lib.call("tg_igemm_" + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
+        lib.call_igemm("tg_igemm_" + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
     close(yd.cpu().numpy(), y_ref, np.abs(x).max() * np.abs(wt).max() * 9 * cin)
 
     # the same forward as ONE 3x3 problem with (output parity, channel) columns (tg_igemm_desc.n_group) and the merged filter
@@ -164,7 +164,7 @@ def test_deconv5x5s2_fwd_dgrad_wgrad(n, h, w, cin, cout, prec):
     wm = torch.full((dm.c_out * 9 * ci_p,), 7.0, device='cuda')
     lib.call("tg_deconv_merge_prep_f32", lib.ptr(wraw), None, cout, cin, ng, dm.c_out, ci_p, (C.c_int32 * 36)(*tapmap), lib.ptr(wm), lib.cur_stream())
     ym = torch.full((n, 2 * h, 2 * w, cout), 7.0, device='cuda')
-    lib.call("tg_igemm_" + prec, dm, lib.ptr(xd), lib.ptr(wm), lib.ptr(bd), lib.ptr(ym), lib.cur_stream())
+    lib.call_igemm("tg_igemm_" + prec, dm, lib.ptr(xd), lib.ptr(wm), lib.ptr(bd), lib.ptr(ym), lib.cur_stream())
     close(ym.cpu().numpy(), y_ref, np.abs(x).max() * np.abs(wt).max() * 9 * cin)
 
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
@@ -174,7 +174,7 @@ def test_deconv5x5s2_fwd_dgrad_wgrad(n, h, w, cin, cout, prec):
     w_t[:, :cin, :cout] = wt.reshape(25, cout, cin).transpose(0, 2, 1)
     dxd = torch.full((n, h, w, ci_p), 7.0, device='cuda')
     wtd = dev(w_t)
-    lib.call("tg_igemm_" + prec, geom.deconv_dgrad(n, h, w, ci_p, co_p), lib.ptr(dyd), lib.ptr(wtd), None,
+    lib.call_igemm("tg_igemm_" + prec, geom.deconv_dgrad(n, h, w, ci_p, co_p), lib.ptr(dyd), lib.ptr(wtd), None,
              lib.ptr(dxd), lib.cur_stream())
     close(dxd.cpu().numpy()[..., :cin], dx_ref, np.abs(dy).max() * np.abs(wt).max() * 25 * cout)
 
@@ -198,7 +198,7 @@ def test_dense_and_identity_layout(prec):
     wt = rng.standard_normal((nout, kdim)).astype(np.float32)      # Wt[n][k]
     yd = torch.zeros((m, nout), device='cuda')
     xd, wd = dev(x), dev(wt)      # keep the device buffers alive across the asynchronous launch
-    lib.call("tg_igemm_" + prec, geom.dense_fwd(m, kdim, nout), lib.ptr(xd), lib.ptr(wd), None, lib.ptr(yd),
+    lib.call_igemm("tg_igemm_" + prec, geom.dense_fwd(m, kdim, nout), lib.ptr(xd), lib.ptr(wd), None, lib.ptr(yd),
              lib.cur_stream())
     y = yd.cpu().numpy()
     np.testing.assert_array_equal(y[:128], _q(prec, wt).T)                    # exact: one product per output
@@ -211,4 +211,126 @@ def test_bad_descriptor_is_rejected():
     d.ld_in = 30
     x = torch.zeros(4, 32, device='cuda')
     with pytest.raises(lib.TgError, match="ld_in"):
-        lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(x), None, lib.ptr(x), lib.cur_stream())
+        lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(x), None, lib.ptr(x), None, 0, lib.cur_stream())
+
+
+# ---- work-unit schedule (csrc/geom.cpp tg::igemm_schedule): tiles cut along K, partial sums through caller-owned scratch, fix-up launch ----
+# Each case names what the schedule is expected to cut; the launch WITH scratch must equal the one-workgroup-per-tile launch (scratch =
+# NULL) up to the fp32 order of the K segments' sum, twice in a row bit for bit (the fix-up adds the segments in a fixed order), and both
+# must equal the oracle (the cases are also shapes of the training step: profiles/r02_launches.csv).
+def _rand(rng, *shape):
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda()
+
+
+def _run_both(lib, name, args, out, colsum=None):
+    """-> (out with scratch, out without, [colsum with, without]); also checks run-to-run bit identity of the cut schedule."""
+    res = []
+    for scratch in (True, True, False):
+        out.fill_(7.0)
+        if colsum is not None:
+            colsum.zero_()
+        lib.call_igemm(name, *args, scratch=scratch)
+        torch.cuda.synchronize()
+        res.append((out.clone(), None if colsum is None else colsum.clone()))
+    assert torch.equal(res[0][0], res[1][0]), "the cut schedule is not deterministic"
+    if colsum is not None:
+        assert torch.equal(res[0][1], res[1][1])
+    return res[0], res[2]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_cut_tiles_of_under_filled_launches(prec):
+    import ctypes as C
+    lib, geom = _tg()
+    rng = np.random.default_rng(5)
+    st = lib.cur_stream()
+    bf = 1 if prec == 'bf16' else 0
+    cases = [
+        # the generator's first input gradient: 225 tiles of 64 x 64 on 512 slots -> every tile cut in two
+        ('under-filled', geom.deconv_dgrad(100, 4, 4, 544, 256), (100, 8, 8, 256), (25 * 544 * 256,), (100, 4, 4, 544)),
+        # a discriminator layer on 50 images of 8x8 (160 -> 128): 100 tiles of 45 K-tiles -> cut in four
+        ('few tiles', geom.conv_fwd(50, 8, 8, 160, 128, 3, 1, 'SAME', act='lrelu'), (50, 8, 8, 160), (128 * 9 * 160,), (50, 8, 8, 128)),
+        # the 2-image tail of a split 130-image classifier launch: 8 x 4 tiles, 72 K-tiles each
+        ('tail of a split launch', geom.conv_fwd(2, 16, 16, 256, 256, 3, 1, 'SAME'), (2, 16, 16, 256), (256 * 9 * 256,), (2, 16, 16, 256)),
+    ]
+    was = lib.call('tg_conv3x3_policy', 2)        # the generic kernel for every shape here
+    try:
+        # launches that fill the chip are left alone (cutting the tiles of a last partial round was measured and rejected: profiles/r03_split_ab.txt)
+        for full in (geom.conv_fwd(153, 16, 16, 256, 64, 3, 1, 'SAME'), geom.conv_fwd(130, 8, 8, 256, 512, 3, 1, 'VALID')):
+            assert lib.call('tg_igemm_workspace_bytes', C.byref(full), 1, None, 0, bf) == 0
+        for tag, d, xs, ws_, ys in cases:
+            need = lib.call('tg_igemm_workspace_bytes', C.byref(d), 1, None, 0, bf)
+            assert need > 0, tag
+            x, w = _rand(rng, *xs), _rand(rng, *ws_) * 0.05
+            bias = _rand(rng, d.c_out)
+            y = torch.empty(ys, device='cuda')
+            (a, _), (b, _) = _run_both(lib, 'tg_igemm_' + prec, (d, lib.ptr(x), lib.ptr(w), lib.ptr(bias), lib.ptr(y), st), y)
+            scale = float(x.abs().max() * w.abs().max()) * d.n_taps * d.ld_in
+            assert float((a - b).abs().max()) <= 3e-5 * scale, (tag, float((a - b).abs().max()), scale)
+            assert float(a.abs().max()) > 0 and not bool((a == 7.0).any()), tag
+    finally:
+        lib.call('tg_conv3x3_policy', was)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_cut_long_parities_of_a_transposed_conv_launch(prec):
+    """four sub-problems of 9 / 6 / 6 / 4 taps in ONE launch (the generator's 5x5 stride-2 transposed convs): the long parities are cut;
+    against the oracle and against the uncut launch."""
+    import ctypes as C
+    lib, geom = _tg()
+    q = lambda a: _q(prec, a)
+    rng = np.random.default_rng(6)
+    n, h, w, cin, cout = 100, 4, 4, 522, 256
+    ci_p, co_p = geom.pad32(cin), geom.pad32(cout)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((5, 5, cout, cin)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    w_pad = np.zeros((25, co_p, ci_p), np.float32)
+    w_pad[:, :cout, :cin] = wt.reshape(25, cout, cin)
+    xd, wd, bd = dev(padc(x, ci_p)), dev(w_pad), dev(padc(bias, co_p))
+    dds = lib.desc_array(geom.deconv_fwd(n, h, w, ci_p, co_p, act='relu'))
+    need = lib.call('tg_igemm_workspace_bytes', C.cast(dds, C.c_void_p), len(dds), None, 0, 1 if prec == 'bf16' else 0)
+    assert need > 0                                             # the schedule cuts something
+    y = torch.empty((n, 2 * h, 2 * w, co_p), device='cuda')
+    (a, _), (b, _) = _run_both(lib, 'tg_igemm_multi_' + prec, (C.cast(dds, C.c_void_p), len(dds), lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(y),
+                                                              lib.cur_stream()), y)
+    y_ref = T.relu(T.conv2d_transpose(q(x), q(wt)) + bias)
+    scale = np.abs(x).max() * np.abs(wt).max() * 9 * cin
+    close(a.cpu().numpy()[..., :cout], y_ref, scale)
+    close(b.cpu().numpy()[..., :cout], y_ref, scale)
+    assert float((a - b).abs().max()) <= 3e-5 * scale
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("n,hw,ci,co,segs", [(6, 8, 256, 256, [128, 256]), (5, 16, 256, 256, [768, 512]), (5, 6, 512, 256, [108, 72])])
+def test_cut_tiles_with_column_sums_and_activation_gradient(prec, n, hw, ci, co, segs):
+    """the mean-only-BN launches (tg_igemm_colsum_* / tg_igemm_actsum_*): the fix-up launch runs their LDS-staged epilogue, column sums per
+    application segment included."""
+    import ctypes as C
+    lib, geom = _tg()
+    rng = np.random.default_rng(7)
+    # (6, 8, 256, 256): 384 rows = 6 x 4 tiles of 64 x 64, 72 K-tiles -> cut; the others: the classifier's layers on five images in two
+    # applications (tests/test_gpu_nets.py), the last one with application boundaries inside tiles
+    sa = (C.c_int32 * 2)(*segs)
+    st = lib.cur_stream()
+    bf = 1 if prec == 'bf16' else 0
+    x, w = _rand(rng, n, hw, hw, ci), _rand(rng, co * 9 * ci) * 0.05
+    yact = _rand(rng, n, hw, hw, co)
+    y = torch.empty((n, hw, hw, co), device='cuda')
+    sums = torch.zeros(2 * len(segs) * co, device='cuda')        # nseg x co doubles
+    d = geom.conv_fwd(n, hw, hw, ci, co, 3, 1, 'SAME')
+    was = lib.call('tg_conv3x3_policy', 2)
+    try:
+        assert lib.call('tg_igemm_workspace_bytes', C.byref(d), 1, sa, len(segs), bf) > 0
+        for name, args in (('tg_igemm_colsum_' + prec, (d, lib.ptr(x), lib.ptr(w), lib.ptr(y), sa, len(segs), lib.ptr(sums), 0, st)),
+                           ('tg_igemm_actsum_' + prec, (d, lib.ptr(x), lib.ptr(w), lib.ptr(yact), lib.ACT['lrelu'], 0.2, lib.ptr(y), sa, len(segs),
+                                                        lib.ptr(sums), 0, st))):
+            (a, sa_), (b, sb_) = _run_both(lib, name, args, y, colsum=sums)
+            scale = float(x.abs().max() * w.abs().max()) * 9 * ci
+            assert float((a - b).abs().max()) <= 3e-5 * scale, name
+            cs_a, cs_b = sa_.view(torch.float64).cpu().numpy(), sb_.view(torch.float64).cpu().numpy()
+            assert np.abs(cs_a - cs_b).max() <= 3e-5 * scale * max(segs), name
+            ref = np.stack([a.cpu().numpy().reshape(-1, co)[:segs[0]].astype(np.float64).sum(0), a.cpu().numpy().reshape(-1, co)[segs[0]:].astype(np.float64).sum(0)])
+            assert np.abs(cs_a.reshape(2, co) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), name      # the sums are of the stored values
+    finally:
+        lib.call('tg_conv3x3_policy', was)

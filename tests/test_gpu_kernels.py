@@ -225,7 +225,7 @@ def test_fused_mean_only_batch_norm_forward_backward(prec, segs, h):
     sums = torch.zeros(16 * len(segs) * cout, device='cuda')         # room for the 8 accumulator replicas of tg_mobn_bwd_f32
     d = geom.conv_fwd(n, h, w, cin, cout, 3, 1, 'SAME')
     was, halo0 = lib.call('tg_conv3x3_policy', 1), lib.call('tg_conv3x3_launches')        # the halo kernel wherever the layer applies
-    lib.call('tg_igemm_colsum_' + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(yd), sa, len(segs), lib.ptr(sums), 0, st())
+    lib.call_igemm('tg_igemm_colsum_' + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(yd), sa, len(segs), lib.ptr(sums), 0, st())
     lib.call('tg_conv3x3_policy', was)
     assert lib.call('tg_conv3x3_launches') - halo0 == int(h in (16, 32))
     pre_hip = yd.cpu().numpy().copy()
@@ -384,7 +384,7 @@ def test_input_gradient_fused_with_mobn_backward_statistics(prec, segs, h, cin, 
     descs = geom.conv_dgrad(n, h, w_, cin, co_p, 3, 1, 'SAME')
     assert len(descs) == 1
     was, halo0 = lib.call('tg_conv3x3_policy', 1), lib.call('tg_conv3x3_launches')        # the halo kernel wherever the layer applies
-    lib.call('tg_igemm_actsum_' + prec, descs[0], lib.ptr(dd), lib.ptr(wd), lib.ptr(yd), lib.ACT['lrelu'], 0.2, lib.ptr(td), sa, len(segs),
+    lib.call_igemm('tg_igemm_actsum_' + prec, descs[0], lib.ptr(dd), lib.ptr(wd), lib.ptr(yd), lib.ACT['lrelu'], 0.2, lib.ptr(td), sa, len(segs),
              lib.ptr(sums), 0, st())
     lib.call('tg_conv3x3_policy', was)
     assert lib.call('tg_conv3x3_launches') - halo0 == int(h in (16, 32))
@@ -452,11 +452,11 @@ def test_halo_kernel_walks_several_tiles_per_workgroup(prec, hw, cin, cout, n, s
     for policy in (1, 2):                             # 1: the halo kernel wherever it applies, 2: never
         was, halo0 = lib.call('tg_conv3x3_policy', policy), lib.call('tg_conv3x3_launches')
         y1 = torch.full((n, hw, hw, cout), 7.0, device='cuda')
-        lib.call('tg_igemm_' + prec, d_act, lib.ptr(x), lib.ptr(w_oti), lib.ptr(bias), lib.ptr(y1), st())
+        lib.call_igemm('tg_igemm_' + prec, d_act, lib.ptr(x), lib.ptr(w_oti), lib.ptr(bias), lib.ptr(y1), st())
         y2, s2 = torch.full((n, hw, hw, cout), 7.0, device='cuda'), torch.zeros(2 * len(segs) * cout, device='cuda')
-        lib.call('tg_igemm_colsum_' + prec, d_lin, lib.ptr(x), lib.ptr(w_oti), lib.ptr(y2), sa, len(segs), lib.ptr(s2), 0, st())
+        lib.call_igemm('tg_igemm_colsum_' + prec, d_lin, lib.ptr(x), lib.ptr(w_oti), lib.ptr(y2), sa, len(segs), lib.ptr(s2), 0, st())
         g3, s3 = torch.full((n, hw, hw, cin), 7.0, device='cuda'), torch.zeros(2 * len(segs) * cin, device='cuda')
-        lib.call('tg_igemm_actsum_' + prec, d_bwd, lib.ptr(dy), lib.ptr(w_hwio), lib.ptr(x), lib.ACT['lrelu'], 0.2, lib.ptr(g3), sa, len(segs),
+        lib.call_igemm('tg_igemm_actsum_' + prec, d_bwd, lib.ptr(dy), lib.ptr(w_hwio), lib.ptr(x), lib.ACT['lrelu'], 0.2, lib.ptr(g3), sa, len(segs),
                  lib.ptr(s3), 0, st())                # the halo kernel needs 128 | output channels: the input gradient of the second case stays generic
         lib.call('tg_conv3x3_policy', was)
         assert lib.call('tg_conv3x3_launches') - halo0 == (2 + int(cin % 128 == 0) if policy == 1 else 0)
@@ -519,11 +519,11 @@ def test_halo_kernel_takes_the_whole_rounds_of_a_launch_and_the_generic_kernel_t
     for policy in (0, 2):
         was, halo0 = lib.call('tg_conv3x3_policy', policy), lib.call('tg_conv3x3_launches')
         y1 = torch.full((n, hw, hw, cout), 7.0, device='cuda')
-        lib.call('tg_igemm_' + prec, d_act, lib.ptr(x), lib.ptr(w_oti), lib.ptr(bias), lib.ptr(y1), st())
+        lib.call_igemm('tg_igemm_' + prec, d_act, lib.ptr(x), lib.ptr(w_oti), lib.ptr(bias), lib.ptr(y1), st())
         y2, s2 = torch.full((n, hw, hw, cout), 7.0, device='cuda'), torch.zeros(2 * len(segs) * cout, device='cuda')
-        lib.call('tg_igemm_colsum_' + prec, d_lin, lib.ptr(x), lib.ptr(w_oti), lib.ptr(y2), sa, len(segs), lib.ptr(s2), 0, st())
+        lib.call_igemm('tg_igemm_colsum_' + prec, d_lin, lib.ptr(x), lib.ptr(w_oti), lib.ptr(y2), sa, len(segs), lib.ptr(s2), 0, st())
         g3, s3 = torch.full((n, hw, hw, cin), 7.0, device='cuda'), torch.zeros(2 * len(segs) * cin, device='cuda')
-        lib.call('tg_igemm_actsum_' + prec, d_bwd, lib.ptr(dy), lib.ptr(w_hwio), lib.ptr(x), lib.ACT['lrelu'], 0.2, lib.ptr(g3), sa, len(segs),
+        lib.call_igemm('tg_igemm_actsum_' + prec, d_bwd, lib.ptr(dy), lib.ptr(w_hwio), lib.ptr(x), lib.ACT['lrelu'], 0.2, lib.ptr(g3), sa, len(segs),
                  lib.ptr(s3), 0, st())
         lib.call('tg_conv3x3_policy', was)
         assert lib.call('tg_conv3x3_launches') - halo0 == (3 if policy == 0 else 0)

@@ -1,25 +1,31 @@
 """The north star's acceptance number on the HIP path (BASELINE.json: "classifier error within +-0.3 pp of the CPU reference at equal
 step count"; reference Training/Train_goodGAN.py:295-351 validation loop, :428-447 _metric).
 
-tests/golden/cifar10_long_k300.npz holds the float64 restatement's free-running run of 300 small-batch iterations on the synthetic
-class-prototype task (fixed initial weights, batches, dropout masks and noise; tests/golden/make_golden_long.py) with its error rate on a
-fixed 1 000-image test split every 25 iterations.  Here the HIP path makes the same run — same inputs, its own fp32 arithmetic, nothing
-synchronised — and is evaluated on the same split with the same injected evaluation noise.  The oracle is not run on the GPU box.
+tests/golden/cifar10_long_<fixture>_<variant>.npz hold free-running 300-iteration runs of the oracle on the synthetic class-prototype
+task — fixed initial weights, batches, dropout masks and noise (tests/golden/make_golden_long.py) — with the error rate on a fixed
+1 000-image test split at the fixture's checkpoints, evaluated in float64 AND in several float32 variants that differ only in the order
+of their sums.  Here the HIP path makes the same runs — same inputs, its own fp32 arithmetic, nothing synchronised — and is evaluated on
+the same split with the same injected evaluation noise.  The oracle is not run on the GPU box.
 
-What two correct implementations can be expected to share (tests/test_gpu_step.py docstring: free trajectories drift through sign-like
-Adam steps and kink flips): NOT the transient — while the error falls from 81 % to 6 % within 25 iterations (3 pp per iteration) a
-lead or lag of a fraction of one iteration is already more than 0.3 pp — but the error rate once the curve has flattened, and that is
-where the acceptance number is checked: at every checkpoint from the first one at which the golden error is below 1 % on, and at the end.
-The transient checkpoints are bounded by the golden curve itself (the HIP error must lie within the golden errors one checkpoint earlier
-and later, widened by 0.3 pp).
+What "equal" can mean for a free-running trajectory is MEASURED on the oracle side, not assumed and not taken from the HIP path: while
+the error falls the run is chaotic (fixture 'k300', iteration 50: float64 5.7 %, the float32 variants 27 % and 65 %; Adam's early steps are
+lr * sign(g), so rounding-level gradient differences become discrete weight differences), on the plateau all variants agree.  Round 2
+asked whether the HIP path's 26 - 69 % at that checkpoint was such divergence or a systematic term of one of its kernels:
+tests/debug/debug_long_horizon_lag.py (profiles/r03_long_horizon_lag.txt) shows both filter-gradient routings at the same rounding-level
+gradient error in every variable of every one of the first 40 iterations when started from identical weights, and the float32 controls
+now show the same spread without any HIP kernel involved.
 
-How sharply "flattened" can be drawn was measured on the HIP path itself (round 2): the same build with its filter gradients routed to
-csrc/wgrad3x3.hip or to the generic kernel — both within 4e-4 of a float64 filter gradient on a scale of 800, the halo kernel slightly
-closer (tests/debug/debug_wgrad3x3_accuracy.py) — gives 85.9 / 68.7 / 0.0 / 0.9 / 0.0 ... % against 81.3 / 25.7 / 0.0 / 0.1 / 0.0 ... %
-(golden 81.0 / 5.7 / 0.0 / 0.0 ...): two equally accurate fp32 summation orders are 0.8 pp apart at iteration 100, one checkpoint after
-the curve has hit zero, and identical from iteration 125 on.  So the +-0.3 pp number is demanded of (1) the final checkpoint, (2) every
-checkpoint from two checkpoints (50 iterations) after the golden curve flattens, (3) the MEAN error over the whole flattened region;
-inside those two settling checkpoints a single checkpoint may deviate by 1.5 pp (about twice the spread measured between the two routings).
+Checks, all derived from the committed control runs (no hand-set window, no exemption):
+  1. every checkpoint: the HIP error lies in the controls' range at that checkpoint and its two neighbours, extended on either side by
+     the width of that range (for n exchangeable runs the chance of a further one falling outside shrinks fast with n; where the controls
+     agree — the plateau — the extension is 0) and by the north star's 0.3 pp;
+  2. the SETTLING ITERATION (first checkpoint from which on the error stays within 0.3 pp of float64's final error) lies in the controls'
+     range of settling iterations extended by its own width: a lead or lag is bounded in iterations;
+  3. the final checkpoint and the mean over the last third of the run are within 0.3 pp of the controls' range (extended by its width: no
+     implementation can be closer to "the" reference than the reference's float32 evaluations are to each other; the width is 0 on
+     'k300') — the acceptance number.
+Fixture 'hard' (class blends: a genuinely ambiguous task whose error does NOT fall to zero, last 100 iterations at 2.5x the batch sizes)
+makes 3. a statement about a classifier that is still imperfect; on 'k300' the plateau is 0.0 %.
 """
 import json
 import os
@@ -34,62 +40,118 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'golden'))
 pytestmark = pytest.mark.gpu
 PP = 0.003 + 1e-9                 # +-0.3 percentage points
-SETTLE = 2                        # checkpoints after the golden curve flattens in which one checkpoint may deviate by SETTLE_PP
-SETTLE_PP = 0.015 + 1e-9
 
 
-def test_error_rate_tracks_the_cpu_reference_over_300_iterations():
+def _state_of(tr):
+    return {n: dict(p=s.p.cpu(), m=s.m.cpu(), v=s.v.cpu(), s=s.s.cpu(), step=s.step.cpu(), ema=None if s.ema is None else s.ema.cpu())
+            for n, s in tr.cx.stores.items()}
+
+
+def _load_state(tr, state):
+    for n, s in tr.cx.stores.items():
+        for k in ('p', 'm', 'v', 's', 'step'):
+            getattr(s, k).copy_(state[n][k])
+        if s.ema is not None:
+            s.ema.copy_(state[n]['ema'])
+
+
+def run_hip(M, fixture, policy=None):
+    """the fixture's run on the HIP path -> ({checkpoint: error rate}, per-iteration losses)."""
     import torch
-    import make_golden_long as M
     from oracle import step_cifar10 as S
+    from tg import lib
     from tg.runtime import InjectedRNG
-    g = np.load(M.path(M.K))
-    steps, ref_err = [int(s) for s in g['eval_steps']], 1.0 - g['eval_acc']
-    assert steps[-1] == M.K and len(g['losses']) == M.K
-    tr = G.fresh_trainer(G.make_config(M.SIZES), S.init_params(0))
-    tr.set_hyper(M.HYPER['lr'], M.HYPER['cla_lr'], M.HYPER['lambda_1'], M.HYPER['lambda_2'])
-    cx = tr.cx
-    xt, yt, noise = M.test_split()
+    xt, yt, noise = M.test_split(fixture)
+    steps = [e for e in M.FIXTURES[fixture]['evals']]
+    total = M.total_steps(fixture)
+    if total not in steps:
+        steps.append(total)
+    err, losses, k, state, tr = {}, [], 0, None, None
+    was = lib.call('tg_conv3x3_policy', policy) if policy is not None else None
+    try:
+        for n_it, sizes in M.FIXTURES[fixture]['phases']:
+            if tr is not None:
+                state = _state_of(tr)
+            tr = G.fresh_trainer(G.make_config(sizes), S.init_params(0) if state is None else None)
+            if state is not None:
+                _load_state(tr, state)               # the next phase's batch sizes: a new trainer (static placeholders) on the same state
+            tr.set_hyper(M.HYPER['lr'], M.HYPER['cla_lr'], M.HYPER['lambda_1'], M.HYPER['lambda_2'])
+            cx = tr.cx
 
-    def error_rate():
-        cx.rng = InjectedRNG({'val/C/noise': noise}, cx.device)
-        return 1.0 - tr.evaluate([(xt, yt)])
+            def error_rate():
+                cx.rng = InjectedRNG({'val/C/noise': noise}, cx.device)
+                return 1.0 - tr.evaluate([(xt, yt)])
 
-    got_err = {0: error_rate()}
-    losses = []
-    for k in range(M.K):
-        b, r = M.inputs(k)
-        cx.rng = InjectedRNG(G.injected_arrays(r), cx.device)
-        tr.feed(b)
-        tr.train_iteration(use_graph=False)
-        if (k + 1) in steps:
-            losses.append(tr.losses())
-            got_err[k + 1] = error_rate()
-    torch.cuda.synchronize()
-    table = [dict(step=s, golden_error=float(e), hip_error=float(got_err[s])) for s, e in zip(steps, ref_err)]
+            if k == 0:
+                err[0] = error_rate()
+            for _ in range(n_it):
+                b, r = M.inputs(k, fixture)
+                cx.rng = InjectedRNG(G.injected_arrays(r), cx.device)
+                tr.feed(b)
+                tr.train_iteration(use_graph=False)
+                losses.append(tr.losses())
+                k += 1
+                if k in steps:
+                    err[k] = error_rate()
+        torch.cuda.synchronize()
+    finally:
+        if was is not None:
+            lib.call('tg_conv3x3_policy', was)
+    return err, np.asarray(losses)
+
+
+def settling_step(steps, errs, level):
+    """first checkpoint from which on every error is <= level."""
+    s = steps[-1]
+    for st, e in zip(reversed(steps), reversed(errs)):
+        if e > level:
+            break
+        s = st
+    return s
+
+
+@pytest.mark.parametrize("fixture", ["k300", "hard"])
+def test_error_rate_stays_inside_the_envelope_of_the_cpu_reference_runs(fixture):
+    import make_golden_long as M
+    ctl = M.load(fixture)
+    assert len(ctl) >= 3, "a float64 run and at least two float32 controls"
+    steps = [int(s) for s in ctl['f64']['eval_steps']]
+    for v in ctl.values():
+        assert [int(s) for s in v['eval_steps']] == steps
+    cerr = {name: 1.0 - v['eval_acc'] for name, v in ctl.items()}            # variant -> errors at the checkpoints
+    got, losses = run_hip(M, fixture)
+    herr = [got[s] for s in steps]
+    table = [dict(step=s, hip_error=float(h), **{name: float(e[i]) for name, e in cerr.items()}) for i, (s, h) in enumerate(zip(steps, herr))]
     dbg = os.path.join(os.path.dirname(HERE), 'gpurun_out')
     if os.path.isdir(dbg):
-        json.dump(dict(table=table, hip_losses_at_checkpoints=[list(map(float, l)) for l in losses],
-                       golden_losses_at_checkpoints=[list(map(float, g['losses'][s - 1])) for s in steps[1:]]),
-                  open(os.path.join(dbg, 'long_horizon.json'), 'w'), indent=1)
+        json.dump(dict(fixture=fixture, table=table, hip_losses=losses.tolist()), open(os.path.join(dbg, 'long_horizon_%s.json' % fixture), 'w'), indent=1)
     # identical weights, deterministic evaluation: the initial error is the same number (an arg-max tie at most)
-    assert abs(got_err[0] - ref_err[0]) <= 1.0 / M.N_TEST + 1e-9, table
-    flat = next(i for i, e in enumerate(ref_err) if i > 0 and e < 0.01)                # first checkpoint of the flattened curve
+    assert abs(herr[0] - cerr['f64'][0]) <= 1.0 / M.N_TEST + 1e-9, table[0]
+    # 1. per checkpoint, against the controls' range in a window of one checkpoint either side
+    all_err = np.stack(list(cerr.values()))                                   # [variant, checkpoint]
     for i, s in enumerate(steps):
-        if i == 0:
-            continue
-        if i >= flat:
-            bound = SETTLE_PP if i < flat + SETTLE else PP
-            assert abs(got_err[s] - ref_err[i]) <= bound, ('flattened curve', table)   # the acceptance number (module docstring)
-        else:                                                                          # transient: inside the golden curve's own neighbourhood
-            lo = min(ref_err[i - 1], ref_err[i], ref_err[i + 1]) - PP
-            hi = max(ref_err[i - 1], ref_err[i], ref_err[i + 1]) + PP
-            assert lo <= got_err[s] <= hi, ('transient', table)
-    assert abs(got_err[M.K] - ref_err[-1]) <= PP, table
-    tail = [i for i in range(len(steps)) if i >= flat]
-    assert abs(np.mean([got_err[steps[i]] for i in tail]) - np.mean([ref_err[i] for i in tail])) <= PP, ('mean over the flattened region', table)
-    # losses at the checkpoints stay O(1)-close to the golden trajectory's (GAN losses fluctuate; bound = the spread of the golden
-    # losses over the neighbouring 25 iterations)
-    for l, s in zip(losses, steps[1:]):
-        window = g['losses'][max(0, s - 25):min(M.K, s + 25)]
-        assert np.all(np.abs(np.asarray(l) - g['losses'][s - 1]) <= 3.0 * window.std(axis=0) + 0.05), (s, l, g['losses'][s - 1])
+        win = all_err[:, max(0, i - 1):i + 2]
+        lo, hi = float(win.min()), float(win.max())
+        w = hi - lo
+        assert lo - w - PP <= herr[i] <= hi + w + PP, ('checkpoint', s, herr[i], (lo, hi), table)
+    # 2. the settling iteration
+    level = float(cerr['f64'][-1]) + PP
+    c_settle = [settling_step(steps, list(e), level) for e in cerr.values()]
+    h_settle = settling_step(steps, herr, level)
+    ws = max(c_settle) - min(c_settle)
+    assert min(c_settle) - ws <= h_settle <= max(c_settle) + ws, ('settling iteration', h_settle, sorted(c_settle), table)
+    # 3. the acceptance number: the end of the run and the mean over its last third
+    tail = [i for i, s in enumerate(steps) if s > steps[-1] * 2 // 3]
+    for name, idx in (('final', [len(steps) - 1]), ('mean over the last third', tail)):
+        c = [float(np.mean(e[idx])) for e in cerr.values()]
+        h = float(np.mean([herr[i] for i in idx]))
+        w = max(c) - min(c)                          # 0 where the reference reproduces itself ('k300'): then this IS +-0.3 pp
+        assert min(c) - w - PP <= h <= max(c) + w + PP, (name, h, (min(c), max(c)), table)
+    # the losses stay on the controls' scale (GAN losses fluctuate: bound = the controls' spread around float64 over the neighbouring
+    # 25 iterations, per loss)
+    ref = ctl['f64']['losses']
+    dev = np.max([np.abs(v['losses'] - ref) for n, v in ctl.items() if n != 'f64'], axis=0)      # [iteration, 3]
+    for k in range(24, len(losses), 25):
+        lo, hi = max(0, k - 25), min(len(losses), k + 25)
+        allowed = 2.0 * dev[lo:hi].max(axis=0) + ref[lo:hi].std(axis=0) + 0.05
+        assert np.all(np.abs(losses[k] - ref[k]) <= allowed), (k + 1, losses[k], ref[k], allowed)

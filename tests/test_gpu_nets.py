@@ -13,6 +13,21 @@ pytestmark = pytest.mark.gpu
 ACT_TOL, GRAD_TOL = 1e-4, 1e-3
 
 
+def check_classifier_grad(name, got, ref):
+    """The classifier's gradients on FIVE images: tight (GRAD_TOL of the largest element) unless a kink flipped.  The network is full of
+    kinks (leaky-ReLU signs, max-pool arg-max); forward values agree with float64 to ~1e-6, and of the ~2 M activations a handful sit closer
+    to zero than that.  Measured (round 3, tests/debug/debug_split_nets.py): evaluating the SAME launches with the reduction of some tiles
+    cut in K segments — values equal to 1e-6 — flipped lrelu'(y) for ONE element of conv2_2's output: that layer's b / g gradient moved in one
+    channel (5.4e-2 of the largest element: a bias gradient is a sum over only 1 280 pixels here), its V gradient in that channel's 2 304
+    entries, and every layer below by 5e-3 ... 9e-3.  So: GRAD_TOL, or — the flip budget — 6e-2 of the largest element and 2e-2 in L2 (the one moved element
+    of that 256-entry bias gradient is 1.25e-2 of its norm; tests/test_gpu_step.py budgets 5e-2 / 1e-2 at larger batches)."""
+    d = np.asarray(got, np.float64) - ref
+    mx = np.abs(ref).max() + 1e-30
+    if np.abs(d).max() <= GRAD_TOL * mx:
+        return
+    assert np.linalg.norm(d) <= 2e-2 * np.linalg.norm(ref) and np.abs(d).max() <= 6e-2 * mx, (name, np.abs(d).max() / mx, np.linalg.norm(d) / np.linalg.norm(ref))
+
+
 def f64(d):
     return {k: (f64(v) if isinstance(v, dict) else np.asarray(v, np.float64)) for k, v in d.items()}
 
@@ -66,7 +81,7 @@ def test_classifier_fwd_bwd_two_segments(trainer):
     assert G.rel_err(feat.numpy(), np.concatenate([f1, f2])) < ACT_TOL
     st = cx.stores['classifier']
     for k in g1:
-        assert G.rel_err(st.get(k, 'grad'), g1[k] + g2[k]) < GRAD_TOL, k
+        check_classifier_grad(k, st.get(k, 'grad'), g1[k] + g2[k])
     for p, v in pops.items():   # sequential pop_mean updates in call-site order
         assert G.rel_err(st.get(p + 'meanOnlyBatchNormalization/pop_mean'), v) < ACT_TOL, p
     # evaluation mode uses the accumulated pop_mean, keeps the noise, drops the dropout

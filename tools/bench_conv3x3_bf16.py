@@ -2,7 +2,7 @@
 """The classifier's 3x3 layers on the halo kernels (csrc/conv3x3_bf16.hip, csrc/wgrad3x3.hip), N = 250 images (TG_BENCH_N), standard-normal
 operands: TFLOP/s of tg_igemm_bf16 / tg_igemm_colsum_bf16 / tg_igemm_f32 (forward) and tg_wgrad_bf16 / tg_wgrad_f32 (filter gradient, pixel
 split from tg_wgrad_splits[_bf16]).  TG_BENCH_ONLY=<bf16|bf16_colsum|f32|wgrad_bf16|wgrad_f32> runs one of them; the generic kernels for
-comparison: TG_NO_CONV3X3_BF16=1 / TG_NO_CONV3X3_F32=1 / TG_NO_WGRAD3X3=1 (TG_CONV3X3_STAGED=1: the one-tile-per-workgroup form).  One JSON
+comparison: TG_NO_CONV3X3_BF16=1 / TG_NO_CONV3X3_F32=1 / TG_NO_WGRAD3X3=1.  One JSON
 line per layer; bf16 fractions against 2 500 TFLOP/s dense bf16 (MI355X_MICROARCH.md)."""
 import ctypes as C
 import json
@@ -48,11 +48,12 @@ for name, hw, ci, co in LAYERS:
     dw = geom.conv_wgrad(N, hw, hw, ci, co, 3, 1, 'SAME')
     ns, ns16 = geom.wgrad_splits(dw), geom.wgrad_splits(dw, True)
     slab = torch.empty(max(ns, ns16) * 9 * ci * co, device='cuda')
+    wpk = torch.empty(max(lib.call('tg_igemm_workspace_bytes', C.byref(d), 1, None, 0, 1), 16) // 4, device='cuda')   # caller-owned scratch of the bf16 3x3 kernel
     for tag, fn in (('wgrad_bf16', lambda: lib.call('tg_wgrad_bf16', dw, lib.ptr(x), lib.ptr(y), lib.ptr(slab), ns16, st)),
                     ('wgrad_f32', lambda: lib.call('tg_wgrad_f32', dw, lib.ptr(x), lib.ptr(y), lib.ptr(slab), ns, st)),
-                    ('bf16', lambda: lib.call('tg_igemm_bf16', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st)),
-                    ('bf16_colsum', lambda: lib.call('tg_igemm_colsum_bf16', dc, lib.ptr(x), lib.ptr(w), lib.ptr(y), seg, 1, lib.ptr(sums), 0, st)),
-                    ('f32', lambda: lib.call('tg_igemm_f32', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st))):
+                    ('bf16', lambda: lib.call('tg_igemm_bf16', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), lib.ptr(wpk), wpk.numel() * 4, st)),
+                    ('bf16_colsum', lambda: lib.call('tg_igemm_colsum_bf16', dc, lib.ptr(x), lib.ptr(w), lib.ptr(y), seg, 1, lib.ptr(sums), 0, lib.ptr(wpk), wpk.numel() * 4, st)),
+                    ('f32', lambda: lib.call('tg_igemm_f32', d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), None, 0, st))):
         if only and tag != only:
             continue
         ms = timeit(fn)

@@ -36,7 +36,7 @@ for name, n, hw, ci, co in LAYERS:
         else:
             os.environ["TG_IGEMM_TILE"] = tile
         try:
-            ms = timeit(lambda: lib.call("tg_igemm_multi_f32", C.cast(dds, C.c_void_p), len(dds), lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st))
+            ms = timeit(lambda: lib.call("tg_igemm_multi_f32", C.cast(dds, C.c_void_p), len(dds), lib.ptr(x), lib.ptr(w), None, lib.ptr(y), None, 0, st))
             print("%-22s tile %-8s %7.3f ms %6.1f TFLOP/s" % (name, tile or "model", ms, fl / ms / 1e9))
         except lib.TgError as e:
             print(name, tile, "n/a")

@@ -31,11 +31,11 @@ for name, hw, ci, co in LAYERS:
         st = lib.cur_stream()
         fl = 2.0 * n * hw * hw * 25 * ci * co
         dds = lib.desc_array(geom.deconv_fwd(n, hw, hw, ci, co))
-        ms = timeit(lambda: lib.call("tg_igemm_multi_f32", C.cast(dds, C.c_void_p), len(dds), lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st))
+        ms = timeit(lambda: lib.call("tg_igemm_multi_f32", C.cast(dds, C.c_void_p), len(dds), lib.ptr(x), lib.ptr(w), None, lib.ptr(y), None, 0, st))
         # the four parities as four separate launches (no imbalance inside a launch, but four tails)
         singles = [lib.desc_array([d]) for d in geom.deconv_fwd(n, hw, hw, ci, co)]
         def four():
             for d1 in singles:
-                lib.call("tg_igemm_multi_f32", C.cast(d1, C.c_void_p), 1, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st)
+                lib.call("tg_igemm_multi_f32", C.cast(d1, C.c_void_p), 1, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), None, 0, st)
         ms4 = timeit(four)
         print("%-22s n=%5d  one launch %7.3f ms %6.1f TFLOP/s   four launches %7.3f ms %6.1f TFLOP/s" % (name, n, ms, fl / ms / 1e9, ms4, fl / ms4 / 1e9), flush=True)

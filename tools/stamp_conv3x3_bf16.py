@@ -1,4 +1,4 @@
-"""Diagnostic: cycles per phase of conv3x3_bf16_kernel (libtg_stamp.so, -DTG_STAMP): prologue load issue, prologue (until the first barrier),
+"""Diagnostic: cycles per phase of conv3x3_pipe_kernel (libtg_stamp.so, -DTG_STAMP): prologue load issue, prologue (until the first barrier),
 K loop, epilogue — wave 0 of the first 64 workgroups, median."""
 import ctypes as C, os, sys
 os.environ['TG_LIB'] = 'libtg_stamp.so'
@@ -12,8 +12,9 @@ N = 250
 for name, hw, ci, co in (("conv1_2", 32, 128, 128), ("conv2_2", 16, 256, 256)):
     x = torch.randn(N, hw, hw, ci, device='cuda'); w = torch.randn(co, 9, ci, device='cuda') * 0.05
     d = geom.conv_fwd(N, hw, hw, ci, co, 3, 1, 'SAME'); y = torch.empty(N, hw, hw, co, device='cuda')
+    wpk = torch.empty(max(lib.call('tg_igemm_workspace_bytes', C.byref(d), 1, None, 0, 1), 16) // 4, device='cuda')
     for _ in range(5):
-        lib.call("tg_igemm_bf16", d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), lib.cur_stream())
+        lib.call("tg_igemm_bf16", d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), lib.ptr(wpk), wpk.numel() * 4, lib.cur_stream())
     torch.cuda.synchronize()
     buf = (C.c_uint64 * 512)()
     L.tg_debug_read_conv_stamps.argtypes = [C.POINTER(C.c_uint64)]
@@ -21,19 +22,8 @@ for name, hw, ci, co in (("conv1_2", 32, 128, 128), ("conv2_2", 16, 256, 256)):
     t = np.array(list(buf), dtype=np.float64).reshape(8, 64)
     d_ = np.diff(t[:5], axis=0)
     med = np.median(d_, axis=1)
-    if os.environ.get('TG_CONV3X3_SYMMETRIC'):
-        steps = (ci // 64) * (3 if os.environ.get('TG_CONV3X3_BM', '256') == '256' else 9)
-        la, lm = np.median(t[5]), np.median(t[6])
-        sb = np.array([int(v) for v in t[7]], dtype=np.uint64)
-        ls, lb = np.median(sb >> np.uint64(32)), np.median(sb & np.uint64(0xffffffff))
-        print("   per step (wave 0): load issue %.0f | reads + MFMA %.0f | cvt + LDS write %.0f | barrier %.0f" % (la / steps, lm / steps, ls / steps, lb / steps))
-    elif not os.environ.get('TG_CONV3X3_STAGED'):   # persistent tile-pipelined kernel: consumer wave 0, sums over the workgroup's tiles
+    if True:                                  # persistent tile-pipelined kernel: consumer wave 0, sums over the workgroup's tiles
         m = np.median(t[:6], axis=1)
         steps = (ci // 64) * 3
         print("%s: %d tiles per workgroup | wait for the first operands %.0f | K loops %.0f per tile (%.0f per step; at barriers %.0f per step) | epilogue %.0f per tile | "
               "total %.0f per tile (s_memtime ticks)" % (name, m[5], m[0], m[1] / m[5], m[1] / m[5] / steps, m[2] / m[5] / steps, m[3] / m[5], m[4] / m[5]))
-        continue
-    else:                                     # role-specialised kernel: consumer wave 0 — set-up, wait for the first operands, K loop, epilogue
-        steps = (ci // 64) * 3
-    print("%s: set-up %.0f | until first barrier %.0f | K loop %.0f (%.0f per step, %d steps) | epilogue %.0f | total %.0f ticks (s_memtime, 100 MHz)" %
-          (name, med[0], med[1], med[2], med[2] / steps, steps, med[3], med.sum()))

@@ -11,7 +11,7 @@ for name, hw, ci, co in (("conv1_2", 32, 128, 128), ("conv2_2", 16, 256, 256)):
     x = torch.randn(N, hw, hw, ci, device='cuda'); w = torch.randn(co, 9, ci, device='cuda') * 0.05
     d = geom.conv_fwd(N, hw, hw, ci, co, 3, 1, 'SAME'); y = torch.empty(N, hw, hw, co, device='cuda')
     for _ in range(5):
-        lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), lib.cur_stream())
+        lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), None, 0, lib.cur_stream())
     torch.cuda.synchronize()
     buf = (C.c_uint64 * 64)()
     L.tg_debug_read_stamps.argtypes = [C.POINTER(C.c_uint64)]

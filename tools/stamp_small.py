@@ -13,12 +13,12 @@ for name, N, hw, ci, co in (("d_conv0 32ch", 100, 32, 32, 32), ("d_conv2 64->64 
     x = torch.randn(N, hw, hw, ci, device='cuda'); w = torch.randn(co, 9, ci, device='cuda') * 0.05
     d = geom.conv_fwd(N, hw, hw, ci, co, 3, 1, 'SAME'); y = torch.empty(N, hw, hw, co, device='cuda')
     for _ in range(5):
-        lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), lib.cur_stream())
+        lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), None, 0, lib.cur_stream())
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(20):
-        lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), lib.cur_stream())
+        lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), None, 0, lib.cur_stream())
     b.record(); torch.cuda.synchronize()
     buf = (C.c_uint64 * 64)()
     L.tg_debug_read_stamps(buf)

@@ -48,7 +48,7 @@ for (M, N, taps, ld, h, w, s), cnt in sorted(shapes.items(), key=lambda kv: -kv[
     wt = torch.randn(N, taps, ld, device='cuda') * 0.05
     y = torch.empty(n, d.h_out, d.w_out, N, device='cuda')
     st = lib.cur_stream()
-    call = lambda: lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(wt), None, lib.ptr(y), st)
+    call = lambda: lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(wt), None, lib.ptr(y), None, 0, st)
     os.environ.pop("TG_IGEMM_TILE", None)
     t_model = timeit(call)
     res = {}

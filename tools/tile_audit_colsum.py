@@ -33,7 +33,7 @@ for name, segs, hw, ci, co, pad in (("conv1_2 C-phase", (50, 100, 100), 32, 128,
     sums = torch.zeros(len(segs) * co, dtype=torch.float64, device='cuda')
     seg = (C.c_int32 * len(segs))(*[s * ho * ho for s in segs])
     st = lib.cur_stream()
-    call = lambda: lib.call("tg_igemm_colsum_f32", d, lib.ptr(x), lib.ptr(w), lib.ptr(y), seg, len(segs), lib.ptr(sums), 0, st)
+    call = lambda: lib.call("tg_igemm_colsum_f32", d, lib.ptr(x), lib.ptr(w), lib.ptr(y), seg, len(segs), lib.ptr(sums), 0, None, 0, st)
     fl = 2.0 * n * ho * ho * co * 9 * ci
     os.environ.pop("TG_IGEMM_TILE", None)
     timeit(call)

@@ -19,7 +19,7 @@ for name, hw, ci, co in (("dconv1 8x8x288->128", 8, 288, 128), ("dconv0 4x4x544-
         dl = geom.deconv_fwd(n, hw, hw, ci, co)
         dds = lib.desc_array(dl)
         for _ in range(3):
-            lib.call("tg_igemm_multi_f32", C.cast(dds, C.c_void_p), len(dds), lib.ptr(x), lib.ptr(w), None, lib.ptr(y), lib.cur_stream())
+            lib.call("tg_igemm_multi_f32", C.cast(dds, C.c_void_p), len(dds), lib.ptr(x), lib.ptr(w), None, lib.ptr(y), None, 0, lib.cur_stream())
         torch.cuda.synchronize()
         bm, bn = (int(v) for v in tile.split(',')) if tile else (0, 0)
         nb = 8192

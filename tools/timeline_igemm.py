@@ -10,7 +10,7 @@ N, hw, ci, co = 250, 32, 128, 128
 x = torch.randn(N, hw, hw, ci, device='cuda'); w = torch.randn(co, 9, ci, device='cuda') * 0.05
 d = geom.conv_fwd(N, hw, hw, ci, co, 3, 1, 'SAME'); y = torch.empty(N, hw, hw, co, device='cuda')
 for _ in range(3):
-    lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), lib.cur_stream())
+    lib.call("tg_igemm_f32", d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), None, 0, lib.cur_stream())
 torch.cuda.synchronize()
 nb = 2000
 buf = (C.c_uint64 * (3 * nb))()
