@@ -301,7 +301,7 @@ def main():
     # the dominant launch on its own: the 250-image conv1_2 / conv1_3 launch of conv3x3_pipe_kernel<32> (75.5 GFLOP each) — one row of
     # profiles/rNN_kernel_stats.csv reproduces this figure
     dom = [float(r['ms']) for r in csv.DictReader(open(dump))
-           if r['class'] == 'igemm_f32' and re.match(r"M=(?:%dx)?1024 N=128 K=9x128 " % (SIZES['L_C'] + 2 * SIZES['U_C'] + SIZES['B_G']), r['desc'] or '')]
+           if r['class'] == 'igemm_f32' and (r['desc'] or '').startswith("M=1x%d N=128 K=9x128 in=32x32" % (1024 * (SIZES['L_C'] + 2 * SIZES['U_C'] + SIZES['B_G'])))]
     if not os.environ.get('TG_PROF_DUMP'):
         os.remove(dump)
     s_ = SIZES

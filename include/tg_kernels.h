@@ -146,6 +146,22 @@ int tg_igemm_colsum_bf16(const tg_igemm_desc* d, const float* in, const float* w
                          double* colsum, int colsum_zeroed, void* scratch, int64_t scratch_bytes, void* stream);
 int tg_wgrad_bf16(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream);
 
+/* Backward pass of a 5x5 / stride-2 / 'same' transposed convolution with c_out <= 4 output channels (the generator's image layer,
+ * Model/Good_GAN_cifar10.py:55-57, Model/modle_base.py:246-259) on the vector ALUs — the MFMA tiles pad 3 channels to 32 and do ten times
+ * the layer's arithmetic.  dy: gradient at the layer's pre-activation output [n, 2h, 2w, ld_dy] (c_out channels used); x: the layer input
+ * [n, h, w, ld_x] (ci_p = channel-padded width, a multiple of 32, <= 256; 16 | w, 4 | h).
+ *   dgrad: dx[n,i,j,ci] = sum_{ky,kx,co} dy[n, 2i+ky-1, 2j+kx-1, co] * W[ky,kx,co,ci], W = the [5,5,Cout,Cin] variable itself, times
+ *          scale_a[co] when not NULL (weight norm: tg_wn_scale_tab_f32); all ci_p channels of dx are written (zeros beyond c_in).
+ *   wgrad: dw[25][c_out][c_in] = sum_{n,i,j} dy[n, 2i+ky-1, 2j+kx-1, co] * x[n,i,j,ci] — the layout of the [5,5,Cout,Cin] variable;
+ *          workspace: tg_deconv5x5s2_narrow_wgrad_workspace_bytes bytes of caller-owned scratch (per-block partial sums, reduced in a
+ *          fixed order).  tg_deconv5x5s2_narrow_supported: 1 when the shape is served (else use the tg_igemm_* / tg_wgrad_* path). */
+int tg_deconv5x5s2_narrow_supported(int n, int h, int w, int c_out, int ci_p);
+int64_t tg_deconv5x5s2_narrow_wgrad_workspace_bytes(int n, int h, int w, int c_out, int ci_p);
+int tg_deconv5x5s2_narrow_dgrad_f32(const float* dy, int ld_dy, const float* kernel, const float* scale_a, int n, int h, int w, int c_out, int c_in,
+                                    int ci_p, float* dx, int ld_dx, void* stream);
+int tg_deconv5x5s2_narrow_wgrad_f32(const float* dy, int ld_dy, const float* x, int ld_x, int n, int h, int w, int c_out, int c_in, int ci_p,
+                                    float* workspace, float* dw, void* stream);
+
 /* ---- descriptor builders and workspace sizes (host code, no device work) -------------------------------------------------------
  * Every conv-like op of the hot path as tg_igemm_desc(s), with TensorFlow's padding arithmetic (SAME: out = ceil(in/s), total =
  * max((out-1)*s + k - in, 0), before = total/2, the extra pixel after; VALID: none) — so that a host binding carries no geometry code

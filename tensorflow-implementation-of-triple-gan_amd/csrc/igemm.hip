@@ -57,6 +57,7 @@ __device__ __forceinline__ u32x2 pack4_bf16(u32x4 v) {          // 4 fp32 -> 4 b
 
 constexpr int BK = 32;    // reduction depth per LDS tile
 constexpr int LDT = 36;   // padded LDS row stride (floats)
+constexpr int LDH = 80;   // bf16 variant: LDS row stride in BYTES (32 bf16 = 64 B + 16 B pad: the 16 rows of a ds_read_b128 lane group hit 16 different 16-B bank slots)
 
 #ifdef TG_STAMP
 // Diagnostic build (never shipped): per-phase cycle sums of the K loop for a few workgroups, wave 0, read back with
@@ -261,12 +262,24 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     for (int j = 0; j < BR; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wvoff[j], sw, 0);
   };
   auto sstore = [&](int buf) {
-    float* a = As + buf * BM * LDT + lrow * LDT + seg * 4;
-    float* b = Bs + buf * BN * LDT + lrow * LDT + seg * 4;
+    if constexpr (BF16) {
+      // bf16 LDS images (round 3): the operands are rounded ONCE on the global -> LDS path (v_cvt_pk_bf16_f32, RNE) and a 32-deep row is
+      // 64 bytes — half the LDS bytes of the fp32 image, and the fragments below need no conversion (round 2 converted every fragment
+      // on its way LDS -> registers: eight packed conversions per operand fragment next to the MFMAs)
+      unsigned char* a = reinterpret_cast<unsigned char*>(As) + (buf * BM + lrow) * LDH + seg * 8;
+      unsigned char* b = reinterpret_cast<unsigned char*>(Bs) + (buf * BN + lrow) * LDH + seg * 8;
 #pragma unroll
-    for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4*>(a + 32 * j * LDT) = ra[j];
+      for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x2*>(a + 32 * j * LDH) = pack4_bf16(ra[j]);
 #pragma unroll
-    for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x4*>(b + 32 * j * LDT) = rb[j];
+      for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x2*>(b + 32 * j * LDH) = pack4_bf16(rb[j]);
+    } else {
+      float* a = As + buf * BM * LDT + lrow * LDT + seg * 4;
+      float* b = Bs + buf * BN * LDT + lrow * LDT + seg * 4;
+#pragma unroll
+      for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4*>(a + 32 * j * LDT) = ra[j];
+#pragma unroll
+      for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x4*>(b + 32 * j * LDT) = rb[j];
+    }
   };
 
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
@@ -323,15 +336,16 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     const float* A = As + buf * BM * LDT + wm0 * LDT + frag;
     const float* B = Bs + buf * BN * LDT + wn0 * LDT + frag;
     if constexpr (BF16) {
+      // lane (row r = lane & 31, half h = lane >> 5) supplies k = 16 G + 8 h + (0..7) of 16-deep group G for BOTH operands: one 16-byte read
+      const unsigned char* Ab = reinterpret_cast<const unsigned char*>(As) + (buf * BM + wm0 + (lane & 31)) * LDH + (lane >> 5) * 16;
+      const unsigned char* Bb = reinterpret_cast<const unsigned char*>(Bs) + (buf * BN + wn0 + (lane & 31)) * LDH + (lane >> 5) * 16;
 #pragma unroll
       for (int G = 0; G < BK / 16; ++G) {
         bf16x8 a[MI], b[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          a[mi] = cvt8(*reinterpret_cast<const f32x4*>(A + mi * 32 * LDT + G * 16), *reinterpret_cast<const f32x4*>(A + mi * 32 * LDT + G * 16 + 8));
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * LDH + G * 32);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          b[ni] = cvt8(*reinterpret_cast<const f32x4*>(B + ni * 32 * LDT + G * 16), *reinterpret_cast<const f32x4*>(B + ni * 32 * LDT + G * 16 + 8));
+        for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * LDH + G * 32);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

@@ -9,6 +9,7 @@ from .lib import ACT
 from .runtime import Act, ctx, pad32, seg_array
 
 import os as _os
+_NARROW = _os.environ.get('TG_NARROW_DECONV', '1') != '0'     # A/B switch of csrc/narrow.hip (the generator's image layer, backward)
 _ACTSUM = _os.environ.get('TG_ACTSUM', '1') != '0'      # A/B switch of the input-gradient + activation-derivative + column-sum fusion
 _MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_igemm_actsum_f32', 'tg_wgrad_f32')
 
@@ -87,9 +88,14 @@ def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst, wn=None, defer=Tru
     cx = ctx()
     ns = geom.wgrad_splits(desc, cx.mfma_dtype == 'bf16')      # pixel split and slab size: the library's rule (tg_wgrad_splits[_bf16])
     slab = cx.scratch('slab', geom.wgrad_slab_floats(desc, ns))
-    _call('tg_wgrad_f32', desc, _p(in_act_t), _p(dout_t), _p(slab), ns, cx.stream)
     deferred = defer and (cx.tape is not None or cx._phase_depth > 0)
+    small = desc.n_img * desc.h_v * desc.w_v * desc.ld_in * desc.c_out * desc.n_taps < (1 << 34)      # < 34 GFLOP: the generic kernel's launches
     wide = ns >= 32 and t * c_dim * n_dim <= 65536
+    if deferred and small and not wide:
+        with cx.wgrad_on_side():                                 # beside the input-gradient chain (Context.wgrad_on_side; joined in flush_tails)
+            _call('tg_wgrad_f32', desc, _p(in_act_t), _p(dout_t), _p(slab), ns, cx.stream)
+    else:
+        _call('tg_wgrad_f32', desc, _p(in_act_t), _p(dout_t), _p(slab), ns, cx.stream)
     if deferred and not wide:
         coef = cx.scratch('coef', 2 * n_dim) if wn is not None else None
         j = lib.WnJob(slab.data_ptr(), dst.data_ptr(), wn[0].data_ptr() if wn else None, wn[1].data_ptr() if wn else None,
@@ -305,18 +311,27 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
                   ACT[act], 0.2, cx.stream)
             if needs_w and bias_grad is not None:
                 colstats(0, dpre, co_p, None, 0, y.rows, c_out, [y.rows], s1=bias_grad)
+        # the 3-channel image layer: both gradients on the vector ALUs (csrc/narrow.hip) — the MFMA tiles would pad 3 channels to 32
+        narrow = _NARROW and x.ld == ci_p and bool(lib.call('tg_deconv5x5s2_narrow_supported', x.n, x.h, x.w, c_out, ci_p))
         if needs_w:
-            if wn is None:
+            dw = kernel_grad if wn is None else cx.scratch('dw', 25 * c_out * c_in)
+            if narrow:
+                nws = cx.scratch('nwws', lib.call('tg_deconv5x5s2_narrow_wgrad_workspace_bytes', x.n, x.h, x.w, c_out, ci_p) // 4)
+                _call('tg_deconv5x5s2_narrow_wgrad_f32', _p(dpre), co_p, x.ptr, x.ld, x.n, x.h, x.w, c_out, c_in, ci_p, _p(nws), _p(dw), cx.stream)
+            elif wn is None:
                 filter_grad(geom.deconv_wgrad(x.n, x.h, x.w, co_p, ci_p), dpre, x.t, 25, c_out, c_in, kernel_grad)
             else:
-                dw = cx.scratch('dw', 25 * c_out * c_in)
                 filter_grad(geom.deconv_wgrad(x.n, x.h, x.w, co_p, ci_p), dpre, x.t, 25, c_out, c_in, dw, defer=False)   # consumed right below
+            if wn is not None:
                 with cx.on_side():
                     _call('tg_wn_bwd_tab_f32', _p(dw), _p(kernel), _p(wn[0]), 25, c_out, c_in, _p(kernel_grad), _p(wn[1]), cx.stream)
         if needs_x:
             gx = cx.grad_of(x)
-            _call('tg_igemm_f32', geom.deconv_dgrad(x.n, x.h, x.w, ci_p, co_p, ld_out=gx.ld, n_store=ci_p), _p(dpre), _p(w_tr), None,
-                  gx.ptr, cx.stream)
+            if narrow and gx.ld >= ci_p:
+                _call('tg_deconv5x5s2_narrow_dgrad_f32', _p(dpre), co_p, _p(kernel), _p(scale_a), x.n, x.h, x.w, c_out, c_in, ci_p, gx.ptr, gx.ld, cx.stream)
+            else:
+                _call('tg_igemm_f32', geom.deconv_dgrad(x.n, x.h, x.w, ci_p, co_p, ld_out=gx.ld, n_store=ci_p), _p(dpre), _p(w_tr), None,
+                      gx.ptr, cx.stream)
 
     cx.record(bwd)
     return y

@@ -290,6 +290,12 @@ class Context(object):
         mode = os.environ.get('TG_SIDE_STREAM', '0')
         self.use_side_stream = mode != '0'
         self.side_forward = mode == '1'
+        # Round 3 experiment, OFF by default (TG_WGRAD_SIDE=1): ONLY the small generic filter-gradient launches of a backward pass on the
+        # side stream (beside the input-gradient chain they do not feed), joined once where their slabs are reduced (flush_tails, see
+        # ops.filter_grad).  MEASURED (one MI355X, bench.py 100 steps): replayed hipGraphs 15.08 -> 15.28 ms per step, eager launches
+        # 15.05 -> 14.94 ms: the cross-stream edges cost a captured graph more than the ~20 overlapped launches give (as in round 1).
+        self.wgrad_side = os.environ.get('TG_WGRAD_SIDE', '0') == '1'
+        self._wgrad_side_pending = False
         # fp64 statistics accumulators (fused mean-only BN / batch norm) of one solver run live in ONE arena per phase, zeroed by one
         # launch at the start of the phase instead of one memset per layer and direction (36 -> 3 launches per iteration)
         # forward filter preparation of a whole solver run in two launches: the first pass of a (mode, phase) records the layers that
@@ -613,9 +619,36 @@ class Context(object):
         tape, self.tape = self.tape, []
         return self._run_reverse(tape, stop_at_boundary)
 
+    @contextlib.contextmanager
+    def wgrad_on_side(self):
+        """run the enclosed filter-gradient launch on the side stream, after what the main stream has enqueued so far (its operands are
+        final); the main stream goes on with the input-gradient chain and waits for the side stream in join_wgrad_side()."""
+        if not self.wgrad_side or self._side_depth or not self._phase_depth:
+            yield
+            return
+        ev = self._event('m2w')
+        ev.record(self.torch_stream)
+        self.side_stream.wait_event(ev)
+        self._side_depth += 1
+        torch.cuda.set_stream(self.side_stream)
+        try:
+            yield
+        finally:
+            torch.cuda.set_stream(self.torch_stream)
+            self._side_depth -= 1
+            self._wgrad_side_pending = True
+
+    def join_wgrad_side(self):
+        if self._wgrad_side_pending:
+            ev = self._event('w2m')
+            ev.record(self.side_stream)
+            self.torch_stream.wait_event(ev)
+            self._wgrad_side_pending = False
+
     def flush_tails(self):
         """launch the deferred filter-gradient tails (slab reduction, weight-norm gradient) of the layers whose wgrad has been
         issued since the last flush: three launches for up to 16 layers (tg_filter_grad_tail_multi_f32)."""
+        self.join_wgrad_side()
         jobs, self.tail_jobs = getattr(self, 'tail_jobs', []), []
         if not jobs:
             return

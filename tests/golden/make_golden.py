@@ -63,6 +63,39 @@ def checksums(P):
     return out
 
 
+def run_control(variant, k_steps=K):
+    """the same run evaluated in float32 with the summation order of make_golden_long.VARIANTS[variant]: how far two correct float32
+    evaluations of this free-running trajectory end up from the float64 one (the drift budget of tests/test_gpu_golden.py)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import make_golden_long as ML
+    from oracle import tf_ops as T
+    v = ML.VARIANTS[variant]
+    dt = v['dtype']
+    saved = T.SUM_REVERSED, T._CHUNK_ELEMS
+    T.SUM_REVERSED, T._CHUNK_ELEMS = v['reversed'], T._CHUNK_ELEMS // v['chunk']
+    try:
+        st = S.new_state(ML.cast(S.init_params(0), dt))
+        zca = tuple(np.asarray(a, dt) for a in S.synth_zca())
+        z, y = sample_latents()
+        losses = []
+        for k in range(k_steps):
+            b, r = inputs(k)
+            losses.append(S.train_step(st, ML.cast(b, dt), ML.cast(r, dt), HYPER, zca))
+        x, yt, noise = test_split()
+        logits, _, _ = N.classifier_fwd(st['P'], N.zca_apply(x.astype(dt), *zca), False, {'noise': noise.astype(dt)})
+        return dict(losses=np.asarray(losses, np.float64), sample_final=N.generator_fwd(st['P'], z.astype(dt), y.astype(dt))[0].astype(np.float32),
+                    logits_final=np.asarray(logits, np.float32))
+    finally:
+        T.SUM_REVERSED, T._CHUNK_ELEMS = saved
+
+
+CONTROLS = ('f32a', 'f32b', 'f32c')
+
+
+def controls_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cifar10_small_k10_controls.npz')
+
+
 def run(k_steps=K):
     P32 = S.init_params(0)
     st = S.new_state(f64(P32))
@@ -83,6 +116,14 @@ def run(k_steps=K):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == 'controls':
+        out = {}
+        for v in CONTROLS:
+            for k, a in run_control(v).items():
+                out['%s/%s' % (v, k)] = a
+        np.savez_compressed(controls_path(), **out)
+        print('wrote', controls_path(), os.path.getsize(controls_path()), 'bytes')
+        sys.exit(0)
     g = run()
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cifar10_small_k10.npz')
     np.savez_compressed(path, **{k: (np.asarray(v, np.float32) if k.startswith('sample') else np.asarray(v)) for k, v in g.items()})

@@ -10,8 +10,10 @@ injected from a fixed seed).
 Two fixtures (FIXTURES):
   * 'k300'  — round 2's task (pixel noise 0.25, batches 10/10/10/4/6): the error falls from 90 % to 0 within 75 iterations and stays
               there.  Checkpoints every 5 iterations through the transient, so that a lead or lag is measured in ITERATIONS.
-  * 'hard'  — pixel noise raised until the curve does NOT saturate (plateau error between 5 % and 30 %), the last 100 iterations at
-              2.5x the batch sizes: +-0.3 pp is checked where a classifier that merely "works" does not pass.
+  * 'hard'  — a task whose error does NOT fall to zero: every image is a blend a*proto[y] + (1-a)*proto[y'] with a ~ U(0.5, 1) of its own
+              class and a random other one (images near a = 0.5 are genuinely ambiguous) under pixel noise 0.75; the error settles at
+              10 - 15 % (tuning runs: 13.5 / 14.3 / 12.3 / 11.5 % at iterations 225 ... 300 with pixel noise 0.75, 7 - 8.5 % with 0.4); the
+              last 100 iterations run at 2.5x the batch sizes: +-0.3 pp is checked where a classifier that merely "works" does not pass.
 
 Variants per fixture (VARIANTS) — the SAME run evaluated several ways:
   * 'f64'          — float64 (the golden trajectory),
@@ -51,7 +53,7 @@ FIXTURES = {
     # phases: (number of iterations, batch sizes); evals: checkpoints (iteration counts, 0 is always evaluated)
     'k300': dict(noise=0.25, phases=((300, SIZES),),
                  evals=sorted(set(range(5, 101, 5)) | set(range(25, 301, 25)))),
-    'hard': dict(noise=1.0, phases=((200, SIZES), (100, SIZES_LATE)),
+    'hard': dict(noise=0.75, mix=0.5, phases=((200, SIZES), (100, SIZES_LATE)),
                  evals=sorted(set(range(25, 301, 25)) | set(range(210, 301, 10)))),
 }
 VARIANTS = {

@@ -24,6 +24,20 @@ def test_oracle_reproduces_the_golden_prefix():
     assert g['losses'].shape == (10, 3) and g['sample_final'].shape == (8, 32, 32, 3) and g['logits_final'].shape == (M.N_TEST, 10)
 
 
+def test_float32_controls_of_the_golden_run_are_float32_evaluations_of_it():
+    """tests/golden/cifar10_small_k10_controls.npz (make_golden.py controls): the drift budget of tests/test_gpu_golden.py — the first
+    iteration of every control is the float64 one to float32 accuracy, later ones drift (that is what the file measures)."""
+    import make_golden as M
+    g, c = golden(), np.load(M.controls_path())
+    for v in M.CONTROLS:
+        assert c[v + '/losses'].shape == g['losses'].shape and c[v + '/sample_final'].shape == g['sample_final'].shape
+        np.testing.assert_allclose(c[v + '/losses'][0], g['losses'][0], rtol=2e-3, atol=2e-3)
+        d = float(np.abs(c[v + '/sample_final'] - g['sample_final']).mean())
+        assert 1e-3 < d < 0.2, (v, d)                         # a visibly different, not a diverged trajectory
+    out = M.run_control('f32a', k_steps=1)
+    np.testing.assert_allclose(out['losses'][0], c['f32a/losses'][0], rtol=1e-4, atol=1e-4)
+
+
 def test_goodgan_oracle_reproduces_the_golden_prefix():
     import make_golden_goodgan as M
     for data in M.DATASETS:

@@ -27,13 +27,24 @@ rank = tr.rank
 tr.set_hyper(lambda_1=0.3, lambda_2=0.5)
 full = dict(S.SIZES, **sizes)
 sums = []
+import bench
+from tg import dist as tgdist
+tested = tgdist.self_test(tr.cx.device)                    # the start-up check of an N > 1 bench line
+tr.measure_exposed(True)
 for it in range(3):
     tr.feed(S.synth_batch(1000 * rank + it, full))
     tr.sample_latent()
     tr.train_iteration()
     sums.append([float(st.p.double().sum().item()) for st in tr.cx.stores.values()])
+exposed = tr.exposed_ms()
+tr.measure_exposed(False)
+identical = bench.replicas_identical(tr.cx.stores, tr.cx.device)
+keep = tr.cx.stores['discriminator'].p[5].clone()
+if rank == 1:
+    tr.cx.stores['discriminator'].p[5] = torch.nextafter(keep, keep + 1)      # one replica drifts by ONE ulp in one weight: the check must see it
+broken = bench.replicas_identical(tr.cx.stores, tr.cx.device)
+tr.cx.stores['discriminator'].p[5] = keep
 # data-parallel resume: rank 0 writes, every rank restores — weights are rank 0's, the random streams stay per rank
-from tg import dist as tgdist
 from Training.Saver import Saver
 if rank == 0:
     sv = Saver({ckpt!r})
@@ -43,7 +54,7 @@ tgdist.barrier()
 Saver({ckpt!r}).restore(tr)
 tr.sample_latent()
 torch.cuda.synchronize()
-out = dict(world=tr.world, rank=rank, sums=sums, losses=tr.losses(),
+out = dict(world=tr.world, rank=rank, sums=sums, losses=tr.losses(), tested=tested, exposed=exposed, identical=identical, broken=broken,
            z=tr.z_g_ph.t.cpu().numpy(), rng_state=tr.cx.rng.state.cpu().numpy(),
            p={{k: st.p.cpu().numpy() for k, st in tr.cx.stores.items()}})
 torch.save(out, {out!r} % rank)
@@ -76,6 +87,10 @@ def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, graph):
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
     r = [torch.load(out % i, weights_only=False) for i in range(2)]
     assert r[0]['world'] == r[1]['world'] == 2
+    # bench.py's N > 1 self-validation on the real trainer: exchange self-test, checksum agreement, exposed exchange time (gloo blocks the
+    # host, so every wait is fully exposed: > 0)
+    for q in r:
+        assert q['tested'] == 2 and q['identical'] is True and q['broken'] is False and q['exposed'] > 0.0, {k: q[k] for k in ('tested', 'identical', 'broken', 'exposed')}
     assert r[0]['sums'] == r[1]['sums']                      # bit-identical weights after every iteration
     for k in r[0]['p']:
         np.testing.assert_array_equal(r[0]['p'][k], r[1]['p'][k])

@@ -12,7 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'golden'))
 pytestmark = pytest.mark.gpu
 
-# Free-running bounds (no synchronisation with the oracle), derived as in tests/test_gpu_step.py::test_free_running_three_iterations:
+# CIFAR-10 file (round 3): the free-running bounds — losses per iteration, sampler output, evaluation logits — are the measured spread of
+# the oracle's own float32 evaluations of the same run (cifar10_small_k10_controls.npz), extended by its width; see the test body.
+# MNIST / SVHN files: free-running bounds (no synchronisation with the oracle), derived as in tests/test_gpu_step.py::test_free_running_three_iterations:
 #   * losses: 1.5e-2 * max(1, |ref|) per elapsed iteration — the size of the drift two equally accurate implementations show once
 #     sign-like early Adam steps have put rounding-noise elements 2*lr apart;
 #   * evaluation after K iterations: the logits may differ by the accumulated drift, but an image can only change its arg-max where the
@@ -86,8 +88,13 @@ def test_hip_path_matches_the_golden_vectors():
     losses = np.asarray(losses)
     ref = g['losses']
     assert np.abs(losses[0] - ref[0]).max() <= 2e-4 * np.abs(ref[0]).max()          # first iteration: identical weights
-    # afterwards the two trajectories drift (sign-like first Adam steps, tests/test_gpu_step.py docstring): the per-iteration envelope
-    assert _loss_envelope(losses, ref).all(), np.abs(losses - ref) / np.maximum(1.0, np.abs(ref))
+    # afterwards the trajectories drift (sign-like first Adam steps, tests/test_gpu_step.py docstring).  How far is measured on the oracle
+    # side: the float32 controls of this run (cifar10_small_k10_controls.npz) deviate from float64 by up to 0.08 - 0.15 within the ten
+    # iterations.  At iteration k the HIP path may deviate by what the controls' range — extended by its own width — has reached by then.
+    ctl = np.load(M.controls_path())
+    cdev = np.stack([np.abs(ctl[v + '/losses'] - ref) for v in M.CONTROLS])           # [control, iteration, loss]
+    env = np.maximum.accumulate(2 * cdev.max(axis=0) - cdev.min(axis=0), axis=0) + 2e-4 * np.abs(ref)
+    assert (np.abs(losses - ref) <= env).all(), (np.abs(losses - ref), env)
     for net in ('good_generator', 'discriminator', 'classifier'):
         st = cx.stores[net]
         p = np.concatenate([st.get(k).reshape(-1).astype(np.float64) for k in st.names(True)])
@@ -103,8 +110,14 @@ def test_hip_path_matches_the_golden_vectors():
     _dump('golden_cifar10.json', loss_dev=np.abs(losses - ref) / np.maximum(1.0, np.abs(ref)), sample_mean_abs=np.abs(smp - g['sample_final']).mean(),
           logit_dev_mean=dev.mean(), logit_dev_max=dev.max(), logit_scale=np.abs(g['logits_final']).mean(), acc=acc, acc_golden=float(g['acc_final']),
           acc_allowed=allowed, acc_measured=measured)
-    assert np.abs(smp - g['sample_final']).mean() <= LOSS_DRIFT * M.K / 4                  # tanh images in [-1, 1]: the same drift budget
-    assert dev.mean() <= max(LOSS_DRIFT * M.K, np.abs(g['logits_final']).mean()), (dev.mean(), np.abs(g['logits_final']).mean())
+    # How far a correct float32 evaluation ends up from the float64 trajectory after the ten free-running iterations is MEASURED on the
+    # oracle side (tests/golden/cifar10_small_k10_controls.npz: the oracle in float32 with three summation orders, make_golden.py
+    # controls): sampler output 0.038 / 0.047 / 0.050 mean absolute deviation, evaluation logits 0.064 / 0.064 / 0.080.  The HIP path must
+    # lie in that range extended by its own width (round 2 used a hand-derived 0.0375 for the sampler, which none of the three controls meets).
+    c_smp = [float(np.abs(ctl[v + '/sample_final'] - g['sample_final']).mean()) for v in M.CONTROLS]
+    c_log = [float(np.abs(ctl[v + '/logits_final'].astype(np.float64) - g['logits_final']).max(axis=1).mean()) for v in M.CONTROLS]
+    assert np.abs(smp - g['sample_final']).mean() <= 2 * max(c_smp) - min(c_smp), (np.abs(smp - g['sample_final']).mean(), c_smp)
+    assert dev.mean() <= 2 * max(c_log) - min(c_log), (dev.mean(), c_log)
     assert measured <= allowed + 1e-9 and abs(acc - float(g['acc_final'])) <= allowed + 1e-9, (acc, float(g['acc_final']), allowed)
 
 

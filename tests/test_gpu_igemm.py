@@ -334,3 +334,35 @@ def test_cut_tiles_with_column_sums_and_activation_gradient(prec, n, hw, ci, co,
             assert np.abs(cs_a.reshape(2, co) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), name      # the sums are of the stored values
     finally:
         lib.call('tg_conv3x3_policy', was)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(5, 16, 16, 138, 3), (2, 32, 32, 74, 3), (3, 4, 16, 40, 1), (2, 8, 16, 120, 4)])
+def test_narrow_transposed_conv_backward_on_the_vector_alus(n, h, w, cin, cout):
+    """csrc/narrow.hip: input and filter gradient of a 5x5 / stride-2 transposed conv with <= 4 output channels (the generator's image
+    layer) against the oracle — exact fp32 FMAs, so the fp32 bound of the MFMA kernels applies."""
+    lib, geom = _tg()
+    rng = np.random.default_rng(11)
+    ci_p, co_p = geom.pad32(cin), geom.pad32(cout)
+    assert lib.call('tg_deconv5x5s2_narrow_supported', n, h, w, cout, ci_p) == 1
+    assert lib.call('tg_deconv5x5s2_narrow_supported', n, h, w, 5, ci_p) == 0 and lib.call('tg_deconv5x5s2_narrow_supported', n, h, 24, cout, ci_p) == 0
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((5, 5, cout, cin)) * 0.1).astype(np.float32)
+    dy = rng.standard_normal((n, 2 * h, 2 * w, cout)).astype(np.float32)
+    st = lib.cur_stream()
+    # input gradient, from the [5,5,Cout,Cin] variable itself (and with a per-output-channel weight-norm scale)
+    dyd, wtd, xd = dev(padc(dy, co_p)), dev(wt), dev(padc(x, ci_p))
+    scale = (1 + 0.3 * rng.standard_normal(cout)).astype(np.float32)
+    for sc in (None, scale):
+        dxd = torch.full((n, h, w, ci_p), 7.0, device='cuda')
+        lib.call('tg_deconv5x5s2_narrow_dgrad_f32', lib.ptr(dyd), co_p, lib.ptr(wtd), lib.ptr(dev(sc)) if sc is not None else None, n, h, w, cout, cin, ci_p,
+                 lib.ptr(dxd), ci_p, st)
+        dx = dxd.cpu().numpy()
+        w_eff = wt if sc is None else wt * sc[None, None, :, None]
+        close(dx[..., :cin], T.conv2d_transpose_bwd_input(w_eff, dy), np.abs(dy).max() * np.abs(w_eff).max() * 25 * cout)
+        assert (dx[..., cin:] == 0).all()
+    # filter gradient straight into the [5,5,Cout,Cin] variable's layout
+    need = lib.call('tg_deconv5x5s2_narrow_wgrad_workspace_bytes', n, h, w, cout, ci_p)
+    ws = torch.empty(need // 4, device='cuda')
+    dwd = torch.full((25, cout, cin), 7.0, device='cuda')
+    lib.call('tg_deconv5x5s2_narrow_wgrad_f32', lib.ptr(dyd), co_p, lib.ptr(xd), ci_p, n, h, w, cout, cin, ci_p, lib.ptr(ws), lib.ptr(dwd), st)
+    close(dwd.cpu().numpy().reshape(wt.shape), T.conv2d_transpose_bwd_filter(x, dy, wt.shape), np.abs(x).max() * np.abs(dy).max() * n * h * w)

@@ -6,7 +6,7 @@ R=${1:-r01}
 O=gpurun_out/profiles_$R
 mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
-TG_PROF_DUMP=$O/launches.csv python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --prof-iters 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp -- python3 bench.py --no-cpu-baseline > $O/rp_bench.json 2> $O/rp.err
+TG_PROF_DUMP=$O/launches.csv python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --prof-iters 1 --soak-seconds 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp -- python3 bench.py --no-cpu-baseline --soak-seconds 0 > $O/rp_bench.json 2> $O/rp.err
 cp $O/rp/*/*kernel_stats.csv $O/kernel_stats.csv
 tail -c 400 $O/bench.json
