@@ -332,6 +332,14 @@ int tg_bn_moving_update_f32(const double* sums, int rows, int c, const int32_t* 
 int tg_bn_train_bwd_f32(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
                         const float* gamma, const float* mean_inv, int relu_input, double* sums, int sums_zeroed, float* dgamma, float* dbeta,
                         void* stream);
+/* The same pass with the derivative of the activation that PRODUCED x folded in (x = act(conv + bias) feeding a batch norm: the SVHN /
+ * MNIST classifier's conv -> leaky relu -> BN, the generator's deconv -> relu -> BN; Model/Good_GAN.py:249-350, Model/Good_GAN_cifar10.py:44-53):
+ *   dx = [ gamma*inv*(dy - mean_s(dy) - xhat*mean_s(dy*xhat)) ] * act'(x)      act: TG_ACT_NONE / TG_ACT_RELU / TG_ACT_LRELU (alpha)
+ * is the gradient at the producing layer's PRE-activation output, and — dsum / dbias not NULL — dbias[k] = sum over all rows of dx[:,k] is
+ * that layer's bias gradient: tg_actgrad_bias_f32's read-modify-write pass over the activation disappears.  dsum: scratch of 8*c doubles. */
+int tg_bn_train_bwd_act_f32(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows,
+                            int nseg, const float* gamma, const float* mean_inv, int act, float alpha, double* sums, int sums_zeroed, float* dgamma,
+                            float* dbeta, double* dsum, int dsum_zeroed, float* dbias, void* stream);
 /* batch norm (training mode, biased variance) from s1 = sum x and s2 = sum (x-mean)^2 (modes 0 and 4 above):
  * scale = gamma*inv, shift = beta - mean*scale, mean_inv = [mean | inv];
  * moving statistics updated in place when non-NULL (bessel = use the unbiased variance, the fused 4-D kernel). */

@@ -710,8 +710,11 @@ __global__ void __launch_bounds__(256) bn_moving_update(const double* __restrict
 __global__ void __launch_bounds__(256) bn_train_bwd_apply(const float* __restrict__ dy, int ld_dy, const float* __restrict__ x, int ld_x,
                                                           float* __restrict__ dx, int ld_dx, int c, SegTable st, int chunk,
                                                           const double* __restrict__ sums, const float* __restrict__ gamma,
-                                                          const float* __restrict__ mean_inv, int relu_mask, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta) {
+                                                          const float* __restrict__ mean_inv, int act, float alpha, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, double* __restrict__ dsum) {
+  // act != none: x is the output of a fused activation (relu / leaky relu); dx is then the gradient with respect to the PRE-activation
+  // value: times act'(x).  dsum != NULL: the column sums of dx (= the bias gradient of the layer that produced x) are accumulated into
+  // dsum[REPL][c] (fp64, one atomic per column per workgroup) — tg_actgrad_bias_f32's pass folded into this one.
   int seg, r0, r1;
   if (!bn_chunk(st, chunk, blockIdx.x, &seg, &r0, &r1)) return;
   const int c0 = blockIdx.y * BN_CW;
@@ -751,6 +754,7 @@ __global__ void __launch_bounds__(256) bn_train_bwd_apply(const float* __restric
   __syncthreads();
   const int cgn = (ncol + 3) / 4;
   const int total = (r1 - r0) * cgn;
+  double cs[4] = {0., 0., 0., 0.};                             // dsum: this thread's column group is fixed (256 % cgn == 0, launcher check)
   for (int i = threadIdx.x; i < total; i += 256) {
     const int rr = i / cgn, cg = i - rr * cgn;
     const float4 g = *reinterpret_cast<const float4*>(dy + (int64_t)(r0 + rr) * ld_dy + c0 + cg * 4);
@@ -760,10 +764,28 @@ __global__ void __launch_bounds__(256) bn_train_bwd_apply(const float* __restric
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float t = A[cg * 4 + k] * gs[k] + B[cg * 4 + k] * xs[k] + Cc[cg * 4 + k];
-      if (relu_mask && !(xs[k] > 0.f)) t = 0.f;
+      if (act != TG_ACT_NONE) t *= tgd::act_grad(xs[k], act, alpha);
       v[k] = t;
+      cs[k] += (double)t;
     }
     *reinterpret_cast<float4*>(dx + (int64_t)(r0 + rr) * ld_dx + c0 + cg * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  if (dsum != nullptr) {
+    __shared__ double red[256 * 4];
+    const int cg = threadIdx.x % cgn, rl = threadIdx.x / cgn, lanes = 256 / cgn;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[threadIdx.x * 4 + k] = cs[k];
+    __syncthreads();
+    if (rl == 0) {
+      for (int l = 1; l < lanes; ++l)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cs[k] += red[(l * cgn + cg) * 4 + k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int col = c0 + cg * 4 + k;
+        if (col < c) atomicAdd(dsum + (int64_t)(blockIdx.x % REPL) * c + col, cs[k]);
+      }
+    }
   }
 }
 
@@ -1050,9 +1072,32 @@ int tg_bn_moving_update_f32(const double* sums, int rows, int c, const int32_t* 
   return TG_OK;
 }
 
+static int bn_train_bwd_impl(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
+                             const float* gamma, const float* mean_inv, int act, float alpha, double* sums, int sums_zeroed, float* dgamma, float* dbeta,
+                             double* dsum, int dsum_zeroed, float* dbias, void* stream);
+
 int tg_bn_train_bwd_f32(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
                         const float* gamma, const float* mean_inv, int relu_input, double* sums, int sums_zeroed, float* dgamma, float* dbeta,
                         void* stream) {
+  return bn_train_bwd_impl(dy, ld_dy, x, ld_x, dx, ld_dx, rows, c, seg_rows, nseg, gamma, mean_inv, relu_input ? TG_ACT_RELU : TG_ACT_NONE, 0.f, sums,
+                           sums_zeroed, dgamma, dbeta, nullptr, 0, nullptr, stream);
+}
+
+int tg_bn_train_bwd_act_f32(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows,
+                            int nseg, const float* gamma, const float* mean_inv, int act, float alpha, double* sums, int sums_zeroed, float* dgamma,
+                            float* dbeta, double* dsum, int dsum_zeroed, float* dbias, void* stream) {
+  TG_REQUIRE(act == TG_ACT_NONE || act == TG_ACT_RELU || act == TG_ACT_LRELU, "bn_train_bwd_act: activation %d has no derivative from its output here", act);
+  TG_REQUIRE((dsum == nullptr) == (dbias == nullptr), "bn_train_bwd_act: dsum / dbias must both be given or both be NULL");
+  const int ncol = c < BN_CW ? c : BN_CW;
+  TG_REQUIRE(dsum == nullptr || (c % 4 == 0 && 256 % ((ncol + 3) / 4) == 0 && (c <= BN_CW || c % BN_CW == 0)),
+             "bn_train_bwd_act: the bias-gradient sums need 4 | c and column groups that divide 256 (c=%d)", c);
+  return bn_train_bwd_impl(dy, ld_dy, x, ld_x, dx, ld_dx, rows, c, seg_rows, nseg, gamma, mean_inv, act, alpha, sums, sums_zeroed, dgamma, dbeta, dsum,
+                           dsum_zeroed, dbias, stream);
+}
+
+static int bn_train_bwd_impl(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
+                             const float* gamma, const float* mean_inv, int act, float alpha, double* sums, int sums_zeroed, float* dgamma, float* dbeta,
+                             double* dsum, int dsum_zeroed, float* dbias, void* stream) {
   SegTable st;
   int rc = make_segs(st, seg_rows, nseg, rows);
   if (rc != TG_OK) return rc;
@@ -1065,13 +1110,22 @@ int tg_bn_train_bwd_f32(const float* dy, int ld_dy, const float* x, int ld_x, fl
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * REPL * 2 * nseg * c, s);
     if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn bwd sums)");
   }
+  if (dsum && !dsum_zeroed) {
+    hipError_t e = hipMemsetAsync(dsum, 0, sizeof(double) * REPL * c, s);
+    if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn bwd bias sums)");
+  }
   tg::ProfScope prof(tg::PC_NORM, 0, 20.0 * rows * c, s);
   int chunk; dim3 grid;
   bn_grid(st, rows, c, &chunk, &grid);
   hipLaunchKernelGGL(bn_sums<true>, grid, dim3(256), 0, s, dy, ld_dy, x, ld_x, c, st, chunk, sums);
   TG_CHECK_LAUNCH("bn_sums<bwd>");
-  hipLaunchKernelGGL(bn_train_bwd_apply, grid, dim3(256), 0, s, dy, ld_dy, x, ld_x, dx, ld_dx, c, st, chunk, sums, gamma, mean_inv, relu_input, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_train_bwd_apply, grid, dim3(256), 0, s, dy, ld_dy, x, ld_x, dx, ld_dx, c, st, chunk, sums, gamma, mean_inv, act, alpha, dgamma, dbeta,
+                     dsum);
   TG_CHECK_LAUNCH("bn_train_bwd_apply");
+  if (dsum) {
+    hipLaunchKernelGGL(repl_finalize, dim3((c + 255) / 256), dim3(256), 0, s, dsum, c, dbias);
+    TG_CHECK_LAUNCH("repl_finalize");
+  }
   return TG_OK;
 }
 

@@ -9,6 +9,7 @@ from .lib import ACT
 from .runtime import Act, ctx, pad32, seg_array
 
 import os as _os
+_BNACT = _os.environ.get('TG_BN_ACT_FUSE', '1') != '0'      # A/B switch: activation derivative + bias gradient folded into the batch-norm backward pass
 _NARROW = _os.environ.get('TG_NARROW_DECONV', '1') != '0'     # A/B switch of csrc/narrow.hip (the generator's image layer, backward)
 _ACTSUM = _os.environ.get('TG_ACTSUM', '1') != '0'      # A/B switch of the input-gradient + activation-derivative + column-sum fusion
 _MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_igemm_actsum_f32', 'tg_wgrad_f32')
@@ -191,6 +192,8 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
         return y
     if mobn is not None and train and act is not None and c_out == co_p and c_out <= 512 and len(seg_rows) <= 8 and ld_out == co_p:
         y.grad_sink = (act, alpha, tuple(seg_rows))      # see Act.grad_sink
+    if mobn is None and act in ('relu', 'lrelu') and needs_w and bias_grad is not None and c_out == co_p == ld_out:
+        y.bias_sink = (act, alpha, bias_grad)            # a batch norm behind this layer may fold act' and the bias gradient into its backward
 
     def bwd():
         gy = y.grad
@@ -199,6 +202,8 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
             dpre = gy.t                                   # the loss head already wrote a padded dlogits
             if needs_w and bias_grad is not None:
                 colstats(0, dpre, co_p, None, 0, y.rows, c_out, [y.rows], s1=bias_grad)
+        elif mobn is None and y.grad_is_dpre and gy.ld == co_p:
+            dpre = gy.t                                   # the batch norm behind this layer already applied act' and summed the bias gradient
         else:
             dpre = cx.scratch('dpre', y.rows * co_p)
         if mobn is None and dpre is gy.t:
@@ -290,6 +295,8 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
     cx.main_waits_side()
     y = cx.new_act(x.n, 2 * x.h, 2 * x.w, c_out, ld_out, requires_grad=needs_w or needs_x)
     y.strided_grad_ok = True
+    if act in ('relu', 'lrelu') and needs_w and bias_grad is not None and c_out == co_p == ld_out:
+        y.bias_sink = (act, 0.2, bias_grad)              # see conv2d
     if merged:
         _call('tg_igemm_f32', d, x.ptr, _p(w_m), _p(bias), y.ptr, cx.stream)
     else:
@@ -301,8 +308,13 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
     def bwd():
         gy = y.grad
         assert gy is not None
-        dpre = cx.scratch('dpre', y.rows * co_p)
-        if needs_w and bias_grad is not None and co_p <= 1024:
+        if y.grad_is_dpre and gy.ld == co_p:
+            dpre = gy.t
+        else:
+            dpre = cx.scratch('dpre', y.rows * co_p)
+        if dpre is gy.t:
+            pass
+        elif needs_w and bias_grad is not None and co_p <= 1024:
             zs, zd = cx.zscratch('ab64', 16 * c_out)
             _call('tg_actgrad_bias_f32', gy.ptr, gy.ld, y.ptr if act else None, y.ld, _p(dpre), co_p, y.rows, c_out, ACT[act], 0.2,
                   _p(zs), zd, _p(bias_grad), cx.stream)
@@ -422,6 +434,17 @@ def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_g
         want = trains and gamma_grad is not None
         gx = cx.grad_of(x)
         bsums, zdb = cx.zscratch('bnb64', 32 * nseg * c)
+        sink = x.bias_sink if _BNACT else None
+        if sink is not None and x.ld == gx.ld and c % 4 == 0 and (c <= 256 and 256 % (c // 4) == 0 or c % 256 == 0):
+            # x = act(conv + bias) of the layer in front (Act.bias_sink): this pass also multiplies by act'(x) and sums the columns — gx IS
+            # that layer's pre-activation gradient and its bias gradient is done (no tg_actgrad_bias_f32 pass over the activation)
+            act_, alpha_, bias_grad_ = sink
+            dsum, zds = cx.zscratch('bnd64', 16 * c)                # 8 replicas x c doubles
+            _call('tg_bn_train_bwd_act_f32', gy.ptr, gy.ld, x.ptr, x.ld, gx.ptr, gx.ld, x.rows, c, seg_array(seg_rows), nseg, _p(gamma), _p(mean_inv),
+                  ACT[act_], alpha_, _p(bsums), zdb, _p(gamma_grad) if want else None, _p(beta_grad) if want else None, _p(dsum), zds,
+                  _p(bias_grad_), cx.stream)
+            x.grad_is_dpre = True
+            return
         _call('tg_bn_train_bwd_f32', gy.ptr, gy.ld, x.ptr, x.ld, gx.ptr, gx.ld, x.rows, c, seg_array(seg_rows), nseg, _p(gamma), _p(mean_inv),
               1 if relu_input else 0, _p(bsums), zdb, _p(gamma_grad) if want else None, _p(beta_grad) if want else None, cx.stream)
 

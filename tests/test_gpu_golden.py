@@ -89,11 +89,17 @@ def test_hip_path_matches_the_golden_vectors():
     ref = g['losses']
     assert np.abs(losses[0] - ref[0]).max() <= 2e-4 * np.abs(ref[0]).max()          # first iteration: identical weights
     # afterwards the trajectories drift (sign-like first Adam steps, tests/test_gpu_step.py docstring).  How far is measured on the oracle
-    # side: the float32 controls of this run (cifar10_small_k10_controls.npz) deviate from float64 by up to 0.08 - 0.15 within the ten
-    # iterations.  At iteration k the HIP path may deviate by what the controls' range — extended by its own width — has reached by then.
+    # side: tests/golden/cifar10_small_k10_controls.npz holds the oracle's float32 evaluations of this run with other summation orders
+    # (make_golden.py controls).  After ten iterations any two of the five reference trajectories {float64, four distinct float32} are
+    # 0.12 - 0.27 apart in the evaluation logits (float64 is not closer to the others than they are to each other) — the run is chaotic
+    # at this size.  Yardstick for every free-running quantity: the PAIRWISE distances among the reference trajectories; the HIP path's
+    # distance to the float64 file must not exceed their maximum extended by their spread.  Per iteration k for the losses (running
+    # maximum: what the references have reached by then).
     ctl = np.load(M.controls_path())
-    cdev = np.stack([np.abs(ctl[v + '/losses'] - ref) for v in M.CONTROLS])           # [control, iteration, loss]
-    env = np.maximum.accumulate(2 * cdev.max(axis=0) - cdev.min(axis=0), axis=0) + 2e-4 * np.abs(ref)
+    refs = [ref] + [ctl[v + '/losses'] for v in M.CONTROLS]
+    pair = np.stack([np.abs(a - b) for i, a in enumerate(refs) for b in refs[i + 1:]])          # [pair, iteration, loss]
+    nz = pair.reshape(len(pair), -1).max(axis=1) > 0                                             # (two variants coincide at this batch size)
+    env = np.maximum.accumulate(2 * pair[nz].max(axis=0) - pair[nz].min(axis=0), axis=0) + 2e-4 * np.abs(ref)
     assert (np.abs(losses - ref) <= env).all(), (np.abs(losses - ref), env)
     for net in ('good_generator', 'discriminator', 'classifier'):
         st = cx.stores[net]
@@ -110,14 +116,19 @@ def test_hip_path_matches_the_golden_vectors():
     _dump('golden_cifar10.json', loss_dev=np.abs(losses - ref) / np.maximum(1.0, np.abs(ref)), sample_mean_abs=np.abs(smp - g['sample_final']).mean(),
           logit_dev_mean=dev.mean(), logit_dev_max=dev.max(), logit_scale=np.abs(g['logits_final']).mean(), acc=acc, acc_golden=float(g['acc_final']),
           acc_allowed=allowed, acc_measured=measured)
-    # How far a correct float32 evaluation ends up from the float64 trajectory after the ten free-running iterations is MEASURED on the
-    # oracle side (tests/golden/cifar10_small_k10_controls.npz: the oracle in float32 with three summation orders, make_golden.py
-    # controls): sampler output 0.038 / 0.047 / 0.050 mean absolute deviation, evaluation logits 0.064 / 0.064 / 0.080.  The HIP path must
-    # lie in that range extended by its own width (round 2 used a hand-derived 0.0375 for the sampler, which none of the three controls meets).
-    c_smp = [float(np.abs(ctl[v + '/sample_final'] - g['sample_final']).mean()) for v in M.CONTROLS]
-    c_log = [float(np.abs(ctl[v + '/logits_final'].astype(np.float64) - g['logits_final']).max(axis=1).mean()) for v in M.CONTROLS]
-    assert np.abs(smp - g['sample_final']).mean() <= 2 * max(c_smp) - min(c_smp), (np.abs(smp - g['sample_final']).mean(), c_smp)
-    assert dev.mean() <= 2 * max(c_log) - min(c_log), (dev.mean(), c_log)
+    # sampler output and evaluation logits after the ten iterations: the same pairwise yardstick (measured: sampler 0.020 - 0.050 mean absolute
+    # difference between two reference trajectories, logits 0.12 - 0.27 mean over the images of the largest logit difference; round 2 used a
+    # hand-derived 0.0375 for the sampler, which most pairs of references do not meet)
+    def extended_max(dist, items):
+        d = [dist(a, b) for i, a in enumerate(items) for b in items[i + 1:]]
+        d = [v for v in d if v > 0]
+        return 2 * max(d) - min(d)
+    smps = [g['sample_final'].astype(np.float64)] + [ctl[v + '/sample_final'].astype(np.float64) for v in M.CONTROLS]
+    lgts = [g['logits_final'].astype(np.float64)] + [ctl[v + '/logits_final'].astype(np.float64) for v in M.CONTROLS]
+    b_smp = extended_max(lambda a, b: float(np.abs(a - b).mean()), smps)
+    b_log = extended_max(lambda a, b: float(np.abs(a - b).max(axis=1).mean()), lgts)
+    assert np.abs(smp - g['sample_final']).mean() <= b_smp, (np.abs(smp - g['sample_final']).mean(), b_smp)
+    assert dev.mean() <= b_log, (dev.mean(), b_log)
     assert measured <= allowed + 1e-9 and abs(acc - float(g['acc_final'])) <= allowed + 1e-9, (acc, float(g['acc_final']), allowed)
 
 

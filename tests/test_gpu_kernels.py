@@ -323,6 +323,26 @@ def test_fused_segmented_batch_norm(segs, hw, c, ld):
     np.testing.assert_allclose(dbd.cpu().numpy(), db_ref, rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(mmd.cpu().numpy(), mm, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(mvd.cpu().numpy(), mv, rtol=1e-4, atol=1e-6)
+    # round 3: the same pass with the derivative of the activation that produced x (conv -> leaky relu -> BN) and that layer's bias gradient
+    # folded in (tg_bn_train_bwd_act_f32): dx * act'(x), bias gradient = its column sums; where the column layout allows the sums
+    if c % 4 == 0 and (c <= 256 and 256 % (c // 4) == 0 or c % 256 == 0):
+        for act, alpha in (('lrelu', 0.2), ('relu', 0.0), (None, 0.0)):
+            mult = np.where(x > 0, 1.0, alpha) if act else np.ones_like(x, np.float64)
+            ref = dx_ref * mult
+            dxa = torch.full((n, hw, hw, ld), 7.0, device='cuda')
+            dsum = torch.zeros(16 * c, device='cuda')
+            dbias = torch.full((c,), 7.0, device='cuda')
+            dgd.fill_(7.0); dbd.fill_(7.0)
+            lib.call('tg_bn_train_bwd_act_f32', lib.ptr(dyd), ld, lib.ptr(xd), ld, lib.ptr(dxa), ld, rows, c, sa, len(segs), lib.ptr(gd), lib.ptr(mean_inv),
+                     lib.ACT[act], alpha, lib.ptr(sums), 0, lib.ptr(dgd), lib.ptr(dbd), lib.ptr(dsum), 0, lib.ptr(dbias), st())
+            np.testing.assert_allclose(dxa.cpu().numpy()[..., :c], ref, rtol=2e-4, atol=2e-5)
+            np.testing.assert_allclose(dbias.cpu().numpy(), ref.reshape(-1, c).sum(0), rtol=2e-4, atol=2e-3)
+            np.testing.assert_allclose(dgd.cpu().numpy(), dg_ref, rtol=2e-4, atol=2e-4)        # the batch norm's own gradients are unchanged
+            np.testing.assert_allclose(dbd.cpu().numpy(), db_ref, rtol=2e-4, atol=2e-4)
+    else:
+        with pytest.raises(lib.TgError, match='bias-gradient sums'):
+            lib.call('tg_bn_train_bwd_act_f32', lib.ptr(dyd), ld, lib.ptr(xd), ld, lib.ptr(dxd), ld, rows, c, sa, len(segs), lib.ptr(gd), lib.ptr(mean_inv),
+                     lib.ACT['lrelu'], 0.2, lib.ptr(sums), 0, None, None, lib.ptr(sums), 0, lib.ptr(dbd), st())
 
 
 @pytest.mark.parametrize("rows,c,ld_out,act", [(1000, 32, 32, 'lrelu'), (77, 3, 32, 'tanh'), (5000, 138, 160, None), (64, 1, 32, None)])
