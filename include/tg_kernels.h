@@ -127,6 +127,16 @@ int tg_igemm_actsum_f32(const tg_igemm_desc* d, const float* in, const float* w,
 int tg_igemm_actsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* yact, int act, float alpha, float* out,
                          const int32_t* seg_rows, int nseg, double* colsum, int colsum_zeroed, void* scratch, int64_t scratch_bytes, void* stream);
 
+/* Convolution + bias + activation (none / relu / leaky relu) whose output feeds a training-mode batch norm (the SVHN / MNIST classifier's
+ * conv -> leaky relu -> BN, Model/Good_GAN.py:249-350): the launch of tg_igemm_f32 / _bf16 that ALSO adds the per-(application segment,
+ * channel) sum and sum of squares of its stored output into replica 0 of the batch norm's statistics buffer — `sums` = the
+ * [8][nseg][2][c_out] fp64 buffer of tg_bn_train_f32, zeroed by the call (all replicas) unless sums_zeroed — so that the batch norm
+ * needs no statistics pass of its own: follow with tg_bn_train_apply_f32.  seg_rows as for tg_igemm_colsum_f32. */
+int tg_igemm_bnstat_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, const int32_t* seg_rows, int nseg,
+                        double* sums, int sums_zeroed, void* scratch, int64_t scratch_bytes, void* stream);
+int tg_igemm_bnstat_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, const int32_t* seg_rows, int nseg,
+                         double* sums, int sums_zeroed, void* scratch, int64_t scratch_bytes, void* stream);
+
 /* filter gradient, split over `n_split` pixel ranges:
  * slab[s][t][c][n] = sum_{p in split s} in[pix(p,t),c] * dout[p,n]   (c < ld_in, n < c_out).
  * `dout` is read through (h_out,w_out,ld_out,os,oo) exactly as tg_igemm_f32 writes `out`.
@@ -321,6 +331,11 @@ int tg_mobn_bwd_finalize_f32(const float* sums, const int32_t* seg_rows, int nse
 int tg_bn_train_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int c, const int32_t* seg_rows, int nseg, const float* gamma,
                     const float* beta, float eps, float decay, float* moving_mean, float* moving_var, double* sums, int sums_zeroed, float* mean_inv,
                     void* stream);
+/* tg_bn_train_f32 without its statistics launch: `sums` already holds S0 = sum x, S1 = sum x^2 per (segment, column) — left there by
+ * tg_igemm_bnstat_* (the producing convolution) — in the layout above.  One launch: normalise, mean / inv-std, moving statistics. */
+int tg_bn_train_apply_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int c, const int32_t* seg_rows, int nseg, const float* gamma,
+                          const float* beta, float eps, float decay, float* moving_mean, float* moving_var, const double* sums, float* mean_inv,
+                          void* stream);
 /* One more moving-statistics update from the batch sums a tg_bn_train_f32 launch left in `sums` (same seg_rows / nseg / c / decay; the
  * buffer must not have been cleared since): what TensorFlow does when a later sess.run re-executes the same training-mode batch norm on
  * the same feed and weights (tf.contrib.layers.batch_norm, updates_collections=None, Model/modle_base.py:229-237) while this build

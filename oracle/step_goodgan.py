@@ -24,7 +24,10 @@ def _gen(P, data, b, bn_updates=None):
     return N.seq_fwd(P, N.generator_layers(data), b['z_g'], b['y_g'], {}, True, bn_updates)
 
 
-def d_phase(st, data, b, rnd, hyper):
+def d_phase(st, data, b, rnd, hyper, labels=None):
+    """labels (tests only): {'unl': one-hot [U_C,10], 'unl_d': one-hot [U_D,10]} to use INSTEAD of the arg-max of the classifier's logits —
+    lets a parity test give the oracle's discriminator the labels the implementation under test fed its own, when a near-tie arg-max
+    (random-init logits, bf16 operand noise) came out differently on the two sides."""
     P = st['P']
     CL, DL = N.classifier_layers(data), N.discriminator_layers(data)
     bnu = {}
@@ -32,11 +35,14 @@ def d_phase(st, data, b, rnd, hyper):
     c_unl, _, _ = N.seq_fwd(P, CL, b['x_u_c'], None, rnd['C_unl'], True, bnu)
     c_unl_d, _, _ = N.seq_fwd(P, CL, b['x_u_d'], None, rnd['C_unl_d'], True, bnu)
     N.commit_bn(P, bnu)
+    oh_unl = T.argmax_onehot(c_unl) if labels is None else np.asarray(labels['unl'], c_unl.dtype)
+    oh_unl_d = T.argmax_onehot(c_unl_d) if labels is None else np.asarray(labels['unl_d'], c_unl_d.dtype)
+    st['last_logits'] = {'unl': c_unl, 'unl_d': c_unl_d}
     X_P = np.concatenate([b['x_l_d'], b['x_u_d']], axis=0)
-    Y_P = np.concatenate([b['y_l_d'], T.argmax_onehot(c_unl_d)], axis=0)
+    Y_P = np.concatenate([b['y_l_d'], oh_unl_d], axis=0)
     grads, total = {}, 0.0
     for key, img, y, target, wgt in (('D_real', X_P, Y_P, 1.0, 1.0), ('D_fake', Gimg.reshape((-1,) + X_P.shape[1:]), b['y_g'], 0.0, 0.5),
-                                     ('D_unl', b['x_u_c'], T.argmax_onehot(c_unl), 0.0, 0.5)):
+                                     ('D_unl', b['x_u_c'], oh_unl, 0.0, 0.5)):
         logits, caches, _ = N.seq_fwd(P, DL, img, y, rnd[key], True)
         l, dl = T.bce_mean(logits, np.full_like(logits, target))
         total += wgt * l

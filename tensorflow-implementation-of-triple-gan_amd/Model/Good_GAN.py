@@ -202,7 +202,9 @@ class Good_GAN(model_base.NN_Base):
         lre = self._leaky_relu
 
         def cbr(x, cname, bname, cout, k=3):
-            x = self._conv2d(x, cout, k_h=k, k_w=k, d_h=1, d_w=1, name=cname, activation=lre)
+            # conv -> leaky relu -> batch norm: in training the batch-norm statistics are taken in the convolution's epilogue
+            x = self._conv2d(x, cout, k_h=k, k_w=k, d_h=1, d_w=1, name=cname, activation=lre,
+                             bn_segments=(segments or [x.n]) if train_ph else None)
             return self._batch_norm_contrib(x, name=bname, train=train_ph, segments=segments)
 
         def pool_drop(x, key):

@@ -70,15 +70,17 @@ class NN_Base(object):
                               n_store_ld=(output_size, output_size) if narrow else None)
 
     def _conv2d(self, input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, kernel_initializer=None, name="conv2d",
-                activation=None):
-        """tf.layers.conv2d 'same' + bias (Model/modle_base.py:157-168)."""
+                activation=None, bn_segments=None):
+        """tf.layers.conv2d 'same' + bias (Model/modle_base.py:157-168).  bn_segments (extension): a training-mode _batch_norm_contrib over
+        these application segments follows directly — its statistics pass is taken in this layer's launch (ops.conv2d(bn_stats=True))."""
         assert k_h == k_w and d_h == d_w
         cx = ctx()
         act, alpha = _act_of(activation)
         with cx.variable_scope(name), cx.variable_scope(name):
             tr = cx.trains()
             return ops.conv2d(input_, cx.var('kernel'), cx.var('bias'), output_dim, k_h, d_h, 'SAME', act=act, alpha=alpha,
-                              kernel_grad=cx.var_grad('kernel') if tr else None, bias_grad=cx.var_grad('bias') if tr else None)
+                              kernel_grad=cx.var_grad('kernel') if tr else None, bias_grad=cx.var_grad('bias') if tr else None,
+                              segments=bn_segments if bn_segments else None, bn_stats=bn_segments is not None)
 
     def _deconv2d(self, input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, name="deconv2d", use_bias=True,
                   kernel_initializer=None, activation=None, narrow=False):

@@ -125,6 +125,7 @@ class Train(Train_base):
             k = c.NUM_CLASSES
             oh_unl = Act(oh[:c.BATCH_SIZE_U_C * k], c.BATCH_SIZE_U_C, 1, 1, k, k)
             oh_unl_d = Act(oh[c.BATCH_SIZE_U_C * k:], c.BATCH_SIZE_U_D, 1, 1, k, k)
+            self._d_labels = (oh_unl, oh_unl_d)          # the labels this run's discriminator sees (parity tests read them back)
             ximg = concat_acts([m.as_image(a) for a in (self.x_l_d_ph, self.x_u_d_ph, G, self.x_u_c_ph)])   # X_P | G | x_u_c (:258-271)
             yall = concat_acts([self.y_l_d_ph, oh_unl_d, self.y_g_ph, oh_unl])
             with cx.rng_scoped('D/D'):

@@ -90,6 +90,7 @@ struct ConvParams {
   uint32_t in_bytes, w_bytes, out_bytes;
   const void* wpk;                             // bf16 filter packed as consecutive LDS images (filter_pack_kernel) — conv3x3_pipe_kernel<.., BF16 = true>
   int f32;                                     // 1: exact-fp32 operands (conv3x3_pipe_kernel<..., BF16 = false>)
+  int stat2;                                   // COLSUM launches: 1 = statistics of the ACTIVATED output act(acc + bias): colsum[seg][0][c] += v, colsum[seg][1][c] += v*v (batch norm behind the layer)
 };
 
 int compute_units() {
@@ -163,8 +164,9 @@ __device__ __forceinline__ void barrier_keep() { asm volatile("s_waitcnt vmcnt(%
 // Tile order: XCD x (= blockIdx & 7) owns a contiguous eighth of the tiles (neighbouring tiles share halo rows and all share the filter
 // in that XCD's L2); its 32 workgroups stride through it.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int W, bool COLSUM, bool BF16>
+template <int W, bool COLSUM, bool BF16, bool STAT2 = false>
 __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
+  static_assert(!STAT2 || COLSUM, "STAT2 is a COLSUM mode");
   constexpr int BM = 256, TPS = 3, NG = 3;
   constexpr int KCH = BF16 ? 64 : 32;
   constexpr int UPR = BF16 ? 16 : 8;
@@ -173,10 +175,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
   constexpr int A_BYTES = (HP * 128 + 255) / 256 * 256, B_TAP = BN * 128, B_BYTES = TPS * B_TAP;
   constexpr int A_IT = (HP + RPP - 1) / RPP, B_IT = BN / RPP;
   constexpr int MAIN_BYTES = A_BYTES + 2 * B_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + 2 * 4 * BN * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + (STAT2 ? 2 : 1) * 2 * 4 * BN * 4];
   unsigned char* As = smem;
   unsigned char* Bs = smem + A_BYTES;
-  float* red = reinterpret_cast<float*>(smem + MAIN_BYTES);       // [tile parity][consumer wave][BN] column sums
+  float* red = reinterpret_cast<float*>(smem + MAIN_BYTES);       // [tile parity][consumer wave][BN] column sums (STAT2: followed by the same of the squares)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = p.n_tiles_m * p.n_tiles_n;
@@ -291,7 +293,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
         while (seg < p.nseg - 1 && m0 >= acc_rows) acc_rows += p.seg_rows[++seg];
         const float* rp = red + parity * 4 * BN + lt;
         const float s1 = (rp[0] + rp[BN]) + (rp[2 * BN] + rp[3 * BN]);
-        if (nt * BN + lt < p.n_store) atomicAdd(p.colsum + (int64_t)seg * p.c_out + nt * BN + lt, (double)s1);
+        if constexpr (STAT2) {
+          const float* rq = rp + 2 * 4 * BN;
+          const float s2 = (rq[0] + rq[BN]) + (rq[2 * BN] + rq[3 * BN]);
+          if (nt * BN + lt < p.n_store) {
+            atomicAdd(p.colsum + ((int64_t)seg * 2) * p.c_out + nt * BN + lt, (double)s1);
+            atomicAdd(p.colsum + ((int64_t)seg * 2 + 1) * p.c_out + nt * BN + lt, (double)s2);
+          }
+        } else if (nt * BN + lt < p.n_store) atomicAdd(p.colsum + (int64_t)seg * p.c_out + nt * BN + lt, (double)s1);
       }
     };
     set_tile_a(t);
@@ -515,6 +524,36 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
                 if (!(TG_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, lane_off(ni, r), off, 0);
               }
             }
+        } else if (STAT2) {
+          // batch norm behind the layer: the stored value is v = act(acc + bias) and the statistics are of v (sum and sum of squares per
+          // application segment and channel: the tf.nn.moments / fused batch-norm pass over the activation disappears)
+          const float slope = p.act == TG_ACT_LRELU ? p.alpha : (p.act == TG_ACT_RELU ? 0.f : 1.f);
+          float bias_v[4], cq[4];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const uint32_t bb = __builtin_amdgcn_raw_buffer_load_b32(rs_b, (uint32_t)(n0 + ni * 32 + col) * 4u, 0, 0);
+            bias_v[ni] = __builtin_bit_cast(float, bb);
+            cq[ni] = 0.f;
+          }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t off = pix_off(mi, r);
+#pragma unroll
+              for (int ni = 0; ni < 4; ++ni) {
+                const float x = acc[mi][ni][r] + bias_v[ni];
+                const float v = x > 0.f ? x : slope * x;
+                cs[ni] += v;
+                cq[ni] += v * v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, lane_off(ni, r), off, 0);
+              }
+            }
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const float o = __shfl_xor(cq[ni], 32);
+            if (half == 0) red[2 * 4 * BN + ((k_tile & 1) * 4 + wave) * BN + ni * 32 + col] = cq[ni] + o;
+          }
         } else if (ym) {
           // the multiplier act'(y) is read at the output's own addresses, one (mi, ni) fragment (16 dwords per lane) ahead of its use
           const float slope = p.ymul_act == TG_ACT_LRELU ? p.ymul_alpha : (p.ymul_act == TG_ACT_RELU ? 0.f : 1.f);
@@ -586,10 +625,12 @@ void launch_pipe(ConvParams& p, hipStream_t s) {
   const int tiles = p.n_tiles_m * p.n_tiles_n, cus = compute_units();
   const dim3 grid(tiles < cus ? tiles : cus);                  // one resident workgroup per CU (LDS), each walking its share of the tiles
   if (p.f32) {
-    if (p.colsum) hipLaunchKernelGGL((conv3x3_pipe_kernel<W, true, false>), grid, dim3(512), 0, s, p);
+    if (p.colsum && p.stat2) hipLaunchKernelGGL((conv3x3_pipe_kernel<W, true, false, true>), grid, dim3(512), 0, s, p);
+    else if (p.colsum) hipLaunchKernelGGL((conv3x3_pipe_kernel<W, true, false>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((conv3x3_pipe_kernel<W, false, false>), grid, dim3(512), 0, s, p);
   } else {
-    if (p.colsum) hipLaunchKernelGGL((conv3x3_pipe_kernel<W, true, true>), grid, dim3(512), 0, s, p);
+    if (p.colsum && p.stat2) hipLaunchKernelGGL((conv3x3_pipe_kernel<W, true, true, true>), grid, dim3(512), 0, s, p);
+    else if (p.colsum) hipLaunchKernelGGL((conv3x3_pipe_kernel<W, true, true>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((conv3x3_pipe_kernel<W, false, true>), grid, dim3(512), 0, s, p);
   }
 }
@@ -680,8 +721,9 @@ int64_t conv3x3_bf16_pack_bytes(const tg_igemm_desc* d, int n_desc) {
 
 int conv3x3_bf16_launch(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, double* colsum,
                         const int32_t* seg_rows, int nseg, const float* ymul, int ymul_act, float ymul_alpha, uint32_t in_bytes, uint32_t w_bytes,
-                        uint32_t out_bytes, hipStream_t s, bool bf16, void* scratch, int64_t scratch_bytes) {
+                        uint32_t out_bytes, hipStream_t s, bool bf16, void* scratch, int64_t scratch_bytes, int stat2) {
   ConvParams p;
+  p.stat2 = stat2;
   p.in = in; p.w = w; p.bias = bias; p.out = out; p.colsum = colsum; p.ymul = ymul; p.ymul_act = ymul_act; p.ymul_alpha = ymul_alpha;
   p.nseg = nseg;
   for (int i = 0; i < 8; ++i) p.seg_rows[i] = (seg_rows && i < nseg) ? seg_rows[i] : 0;

@@ -101,6 +101,8 @@ struct IgemmParams {
   const float* ymul;              // COLSUM variant, optional: out = acc * act'(ymul[same position]) (tg_igemm_actsum_*)
   int ymul_act;
   float ymul_alpha;
+  int stat2;                      // COLSUM variant: 1 = the stored value is v = act(acc + bias) and colsum is [nseg][2][c_out]: sums of v and of v*v
+                                  // (statistics of a batch norm behind the layer, tg_igemm_bnstat_*)
   int nseg, seg_rows[8];
   // ---- work units (tg::igemm_schedule, geom.cpp).  A unit is one output tile over a K range; tiles whose K range is cut into ks > 1
   // units leave raw partial accumulators in `ws` and are finished by the fix-up launch (same kernel, FIXUP = true).
@@ -454,6 +456,15 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       const uint32_t off = ((ro & OOB_OFF) || n >= d.n_store) ? OOB_OFF : ro + (uint32_t)n * 4u;
       const float4 tv = *reinterpret_cast<const float4*>(tile + rl * TLD + cg * 4);
       float va[4] = {tv.x, tv.y, tv.z, tv.w};
+      if (p.stat2) {  // batch norm behind the layer: bias + activation here, statistics of the result; rows beyond M must stay exact zeros
+        const bool live = !(ro & OOB_OFF);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = va[e] + ((p.bias != nullptr && n + e < d.n_store) ? p.bias[n + e] : 0.f);
+          va[e] = live ? apply_act(t, d.act, d.alpha) : 0.f;
+        }
+        *reinterpret_cast<float4*>(tile + rl * TLD + cg * 4) = make_float4(va[0], va[1], va[2], va[3]);
+      }
       if (ym) {      // input gradient times the activation derivative of the layer that produced this conv's input
         const u32x4 yb = __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, off, 0, 0);          // masked positions read 0
         const uint32_t y0 = yb.x, y1 = yb.y, y2 = yb.z, y3 = yb.w;
@@ -467,30 +478,44 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
                         __builtin_bit_cast(uint32_t, va[3])};
       __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_o, off, 0, 0);
     }
-    if (ym) __syncthreads();
+    if (ym || p.stat2) __syncthreads();
     // column sums: thread (column c, part q) adds rows q, q + PARTS, ... of its column (masked rows hold exact zeros)
     constexpr int PARTS = 256 / BN;
-    float* red = tile + BM * TLD;                         // [2][PARTS][BN] partial sums, behind the tile
-    static_assert(BM * TLD + 2 * PARTS * BN <= 2 * BM * LDT + 2 * BN * LDT, "partial sums must fit as well");
+    float* red = tile + BM * TLD;                         // [4][PARTS][BN] partial sums (two segments; stat2: also of the squares), behind the tile
+    static_assert(BM * TLD + 4 * PARTS * BN <= 2 * BM * LDT + 2 * BN * LDT, "partial sums must fit as well");
     {
       const int c = tid % BN, q = tid / BN;
-      float s1 = 0.f, s2 = 0.f;
+      float s1 = 0.f, s2 = 0.f, q1 = 0.f, q2 = 0.f;
       for (int rl = q; rl < BM; rl += PARTS) {
         const float v = tile[rl * TLD + c];
-        if (rl < bnd) s1 += v; else s2 += v;
+        if (rl < bnd) { s1 += v; q1 += v * v; } else { s2 += v; q2 += v * v; }
       }
       red[q * BN + c] = s1;
       red[(PARTS + q) * BN + c] = s2;
+      red[(2 * PARTS + q) * BN + c] = q1;
+      red[(3 * PARTS + q) * BN + c] = q2;
     }
     __syncthreads();
     if (tid < BN) {
       const int n = n0 + tid;
-      float s1 = 0.f, s2 = 0.f;
+      float s1 = 0.f, s2 = 0.f, q1 = 0.f, q2 = 0.f;
 #pragma unroll
-      for (int q = 0; q < PARTS; ++q) { s1 += red[q * BN + tid]; s2 += red[(PARTS + q) * BN + tid]; }
+      for (int q = 0; q < PARTS; ++q) {
+        s1 += red[q * BN + tid]; s2 += red[(PARTS + q) * BN + tid];
+        q1 += red[(2 * PARTS + q) * BN + tid]; q2 += red[(3 * PARTS + q) * BN + tid];
+      }
       if (n < d.n_store) {
-        atomicAdd(p.colsum + (int64_t)seg * p.c_out + n, (double)s1);
-        if (two) atomicAdd(p.colsum + (int64_t)(seg + 1) * p.c_out + n, (double)s2);
+        if (p.stat2) {
+          atomicAdd(p.colsum + ((int64_t)seg * 2) * p.c_out + n, (double)s1);
+          atomicAdd(p.colsum + ((int64_t)seg * 2 + 1) * p.c_out + n, (double)q1);
+          if (two) {
+            atomicAdd(p.colsum + ((int64_t)(seg + 1) * 2) * p.c_out + n, (double)s2);
+            atomicAdd(p.colsum + ((int64_t)(seg + 1) * 2 + 1) * p.c_out + n, (double)q2);
+          }
+        } else {
+          atomicAdd(p.colsum + (int64_t)seg * p.c_out + n, (double)s1);
+          if (two) atomicAdd(p.colsum + (int64_t)(seg + 1) * p.c_out + n, (double)s2);
+        }
       }
     }
     return;
@@ -879,7 +904,7 @@ static int head_tail(const tg_igemm_desc* descs, int n_desc, const int32_t* seg_
 
 static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out, void* stream,
                       double* colsum, const int32_t* seg_rows, int nseg, bool bf16 = false, const float* ymul = nullptr, int ymul_act = 0,
-                      float ymul_alpha = 0.f, void* scratch = nullptr, int64_t scratch_bytes = 0) {
+                      float ymul_alpha = 0.f, void* scratch = nullptr, int64_t scratch_bytes = 0, int stat2 = 0) {
   TG_REQUIRE(descs && n_desc >= 1 && n_desc <= MAX_SUB, "igemm: n_desc=%d out of range", n_desc);
   TG_REQUIRE(in && w && out, "igemm: null buffer");
   // A 3x3 layer of the halo kernel's shape whose launch does not fill whole rounds of one workgroup per CU (conv3x3_bf16.hip): the leading
@@ -888,17 +913,18 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
   HeadTail ht;
   if (const int head = head_tail(descs, n_desc, seg_rows, nseg, colsum != nullptr, bf16, &ht)) {
     const int64_t per_img = (int64_t)descs[0].h_in * descs[0].w_in;
-    int rc = igemm_impl(&ht.dh, 1, in, w, bias, out, stream, colsum, colsum ? ht.seg_h : nullptr, ht.nh, bf16, ymul, ymul_act, ymul_alpha, scratch, scratch_bytes);
+    int rc = igemm_impl(&ht.dh, 1, in, w, bias, out, stream, colsum, colsum ? ht.seg_h : nullptr, ht.nh, bf16, ymul, ymul_act, ymul_alpha, scratch, scratch_bytes, stat2);
     if (rc != TG_OK) return rc;
     const int64_t o_in = (int64_t)head * per_img * descs[0].ld_in, o_out = (int64_t)head * per_img * descs[0].ld_out;
     // (the tail is stream-ordered behind the head: both may use the same scratch)
-    return igemm_impl(&ht.dt, 1, in + o_in, w, bias, out + o_out, stream, colsum ? colsum + (int64_t)ht.k0 * descs[0].c_out : nullptr, colsum ? ht.seg_t : nullptr,
-                      ht.nt, bf16, ymul ? ymul + o_out : nullptr, ymul_act, ymul_alpha, scratch, scratch_bytes);
+    return igemm_impl(&ht.dt, 1, in + o_in, w, bias, out + o_out, stream, colsum ? colsum + (int64_t)ht.k0 * descs[0].c_out * (stat2 ? 2 : 1) : nullptr,
+                      colsum ? ht.seg_t : nullptr, ht.nt, bf16, ymul ? ymul + o_out : nullptr, ymul_act, ymul_alpha, scratch, scratch_bytes, stat2);
   }
   IgemmParams p;
   p.in = in; p.w = w; p.bias = bias; p.out = out; p.n_sub = n_desc;
   p.colsum = colsum; p.nseg = nseg;
   p.ymul = ymul; p.ymul_act = ymul_act; p.ymul_alpha = ymul_alpha;
+  p.stat2 = stat2;
   for (int i = 0; i < 8; ++i) p.seg_rows[i] = (seg_rows && i < nseg) ? seg_rows[i] : 0;
   const tg_igemm_desc* d = &descs[0];
   // sub-problems longest first: workgroups are dispatched in index order, so the 9-tap parity of a 5x5 s2 transposed
@@ -970,7 +996,7 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
   tg::ProfScope prof(tg::PC_IGEMM, flops, bytes, s, desc);
   if (halo)
     return tg::conv3x3_bf16_launch(d, in, w, bias, out, colsum, seg_rows, nseg, ymul, ymul_act, ymul_alpha, p.in_bytes, p.w_bytes, p.out_bytes, s, bf16,
-                                   scratch, scratch_bytes);
+                                   scratch, scratch_bytes, stat2);
   p.n_units = sc.n_units; p.n_fix = sc.n_fix; p.nfull = sc.nfull; p.pat_len = sc.pat_len; p.n_pat_split = sc.n_pat_split; p.n_split_sub = sc.n_split_sub;
   for (int i = 0; i < MAX_SUB; ++i) { p.ks[i] = sc.ks[i]; p.split_sub[i] = sc.split_sub[i]; p.first_slot[i] = sc.first_slot[i]; }
   for (int i = 0; i < 16; ++i) { p.pat_sub[i] = sc.pat_sub[i]; p.pat_k[i] = sc.pat_k[i]; p.pat_slot[i] = sc.pat_slot[i]; }
@@ -1061,6 +1087,32 @@ extern "C" int tg_igemm_colsum_f32(const tg_igemm_desc* d, const float* in, cons
 extern "C" int tg_igemm_colsum_bf16(const tg_igemm_desc* d, const float* in, const float* w, float* out, const int32_t* seg_rows, int nseg,
                                     double* colsum, int colsum_zeroed, void* scratch, int64_t scratch_bytes, void* stream) {
   return igemm_colsum_impl(d, in, w, out, seg_rows, nseg, colsum, colsum_zeroed, stream, true, nullptr, 0, 0.f, scratch, scratch_bytes);
+}
+
+// conv + bias + activation whose output feeds a batch norm: the statistics of the ACTIVATED output are taken in the epilogue
+static int igemm_bnstat_impl(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, const int32_t* seg_rows, int nseg,
+                             double* sums, int sums_zeroed, void* scratch, int64_t scratch_bytes, void* stream, bool bf16) {
+  TG_REQUIRE(d && sums && seg_rows && nseg >= 1 && nseg <= 8, "igemm_bnstat: bad args");
+  TG_REQUIRE(d->n_group == 0, "igemm_bnstat: grouped columns are not supported");
+  TG_REQUIRE(d->act == TG_ACT_NONE || d->act == TG_ACT_RELU || d->act == TG_ACT_LRELU, "igemm_bnstat: activation %d is not none / relu / leaky relu", d->act);
+  int tot = 0;
+  for (int i = 0; i < nseg; ++i) { TG_REQUIRE(seg_rows[i] >= 32, "igemm_bnstat: segment %d has %d rows (need at least one 32-row tile)", i, seg_rows[i]); tot += seg_rows[i]; }
+  TG_REQUIRE(tot == d->n_img * d->h_v * d->w_v, "igemm_bnstat: segments sum to %d rows, launch has %d", tot, d->n_img * d->h_v * d->w_v);
+  if (!sums_zeroed) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 8 * 2 * nseg * d->c_out, tg::as_stream(stream));      // all eight replicas of the batch norm's buffer
+    if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn statistics)");
+  }
+  return igemm_impl(d, 1, in, w, bias, out, stream, sums, seg_rows, nseg, bf16, nullptr, 0, 0.f, scratch, scratch_bytes, 1);
+}
+
+extern "C" int tg_igemm_bnstat_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, const int32_t* seg_rows, int nseg,
+                                   double* sums, int sums_zeroed, void* scratch, int64_t scratch_bytes, void* stream) {
+  return igemm_bnstat_impl(d, in, w, bias, out, seg_rows, nseg, sums, sums_zeroed, scratch, scratch_bytes, stream, false);
+}
+
+extern "C" int tg_igemm_bnstat_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, const int32_t* seg_rows, int nseg,
+                                    double* sums, int sums_zeroed, void* scratch, int64_t scratch_bytes, void* stream) {
+  return igemm_bnstat_impl(d, in, w, bias, out, seg_rows, nseg, sums, sums_zeroed, scratch, scratch_bytes, stream, true);
 }
 
 extern "C" int tg_igemm_actsum_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* yact, int act, float alpha, float* out,

@@ -1058,6 +1058,24 @@ int tg_bn_train_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int 
   return TG_OK;
 }
 
+int tg_bn_train_apply_f32(const float* x, int ld_x, float* y, int ld_y, int rows, int c, const int32_t* seg_rows, int nseg, const float* gamma,
+                          const float* beta, float eps, float decay, float* moving_mean, float* moving_var, const double* sums, float* mean_inv,
+                          void* stream) {
+  SegTable st;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(x && y && gamma && beta && sums && mean_inv, "bn_train_apply: null buffer");
+  TG_REQUIRE(c > 0 && ld_x % 4 == 0 && ld_y % 4 == 0 && (c + 3) / 4 * 4 <= ld_x && (c + 3) / 4 * 4 <= ld_y, "bn_train_apply: c=%d vs ld=%d/%d", c, ld_x, ld_y);
+  TG_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_train_apply: moving_mean / moving_var must both be given or both be NULL");
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 8.0 * rows * c, s);
+  int chunk; dim3 grid;
+  bn_grid(st, rows, c, &chunk, &grid);
+  hipLaunchKernelGGL(bn_train_apply, grid, dim3(256), 0, s, x, ld_x, y, ld_y, c, st, chunk, sums, gamma, beta, eps, decay, moving_mean, moving_var, mean_inv);
+  TG_CHECK_LAUNCH("bn_train_apply");
+  return TG_OK;
+}
+
 int tg_bn_moving_update_f32(const double* sums, int rows, int c, const int32_t* seg_rows, int nseg, float decay, float* moving_mean,
                             float* moving_var, void* stream) {
   SegTable st;

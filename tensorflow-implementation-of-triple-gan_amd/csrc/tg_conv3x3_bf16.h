@@ -13,7 +13,7 @@ bool conv3x3_bf16_applicable(const tg_igemm_desc* d, int n_desc, const int32_t* 
 int conv3x3_bf16_split_images(const tg_igemm_desc* d, int n_desc, const int32_t* seg_rows, int nseg, bool bf16);
 int conv3x3_bf16_launch(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, double* colsum,
                         const int32_t* seg_rows, int nseg, const float* ymul, int ymul_act, float ymul_alpha, uint32_t in_bytes, uint32_t w_bytes,
-                        uint32_t out_bytes, hipStream_t s, bool bf16, void* scratch, int64_t scratch_bytes);
+                        uint32_t out_bytes, hipStream_t s, bool bf16, void* scratch, int64_t scratch_bytes, int stat2 = 0);
 // bytes of caller-owned scratch a bf16 launch of these descriptors needs for the packed filter (0: the layer never takes the halo kernel)
 int64_t conv3x3_bf16_pack_bytes(const tg_igemm_desc* d, int n_desc);
 

@@ -152,6 +152,8 @@ def igemm_workspace_bytes(name, args):
     seg, nseg = None, 0
     if '_colsum_' in name:
         seg, nseg = args[4], args[5]
+    elif '_bnstat_' in name:
+        seg, nseg = args[5], args[6]
     elif '_actsum_' in name:
         seg, nseg = args[7], args[8]
     return call('tg_igemm_workspace_bytes', d0, n_desc, seg, nseg, 1 if name.endswith('bf16') else 0)

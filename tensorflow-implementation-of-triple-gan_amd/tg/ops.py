@@ -9,10 +9,11 @@ from .lib import ACT
 from .runtime import Act, ctx, pad32, seg_array
 
 import os as _os
+_BNSTAT = _os.environ.get('TG_BN_STAT_FUSE', '1') != '0'   # A/B switch: batch-norm statistics taken in the producing convolution's epilogue
 _BNACT = _os.environ.get('TG_BN_ACT_FUSE', '1') != '0'      # A/B switch: activation derivative + bias gradient folded into the batch-norm backward pass
 _NARROW = _os.environ.get('TG_NARROW_DECONV', '1') != '0'     # A/B switch of csrc/narrow.hip (the generator's image layer, backward)
 _ACTSUM = _os.environ.get('TG_ACTSUM', '1') != '0'      # A/B switch of the input-gradient + activation-derivative + column-sum fusion
-_MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_igemm_actsum_f32', 'tg_wgrad_f32')
+_MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_igemm_actsum_f32', 'tg_igemm_bnstat_f32', 'tg_wgrad_f32')
 
 
 def _call(name, *args):
@@ -114,11 +115,13 @@ def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst, wn=None, defer=Tru
 # ------------------------------------------------------------------ conv / dense (plain and weight-normalised)
 
 def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=None, mobn=None, segments=None,
-           train=True, kernel_grad=None, bias_grad=None, n_store_ld=None):
+           train=True, kernel_grad=None, bias_grad=None, n_store_ld=None, bn_stats=False):
     """y = act(conv(x, W) + bias)   or, with wn=(g, g_grad) and mobn=(b, b_grad, pop_mean):
        W = g V/||V||; y = act(conv(x, W) - mean_seg + b)            (Model/nn.py:469-520,525-589).
     kernel: HWIO tensor [k,k,c_in,c_out] (flat).  Dense layers are k = 1 on [n,1,1,c].
-    n_store_ld: (n_store, ld_out) override for narrow outputs (D's logit)."""
+    n_store_ld: (n_store, ld_out) override for narrow outputs (D's logit).
+    bn_stats: a training-mode batch norm over `segments` follows directly — its sum / sum-of-squares pass is taken in this launch's
+    epilogue (tg_igemm_bnstat_*) and left in y.bn_sums for batch_norm_train."""
     cx = ctx()
     assert x.ld % 32 == 0, "conv input must be channel-padded to 32"
     c_in, ci_p, co_p = x.c, x.ld, pad32(c_out)
@@ -175,6 +178,11 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
         _call('tg_igemm_colsum_f32', d, x.ptr, _p(w_oti), y.ptr, seg_array(seg_rows), len(seg_rows), _p(sums), zd, cx.stream)
         _call('tg_mobn_apply_f32', y.ptr, y.ld, y.rows, c_out, seg_array(seg_rows), len(seg_rows), _p(sums), _p(b), _p(pop), 0.9, ACT[act],
               alpha, cx.stream)
+    elif (_BNSTAT and bn_stats and mobn is None and act in (None, 'relu', 'lrelu') and c_out == co_p == ld_out and len(seg_rows) <= 8
+          and geom.colsum_supported(d, seg_rows)):
+        bsum, zd = cx.zscratch('bn64', 32 * len(seg_rows) * c_out)     # the batch norm's buffer: 8 replicas x nseg x 2 x c doubles
+        _call('tg_igemm_bnstat_f32', d, x.ptr, _p(w_oti), _p(bias), y.ptr, seg_array(seg_rows), len(seg_rows), _p(bsum), zd, cx.stream)
+        y.bn_sums = (bsum, tuple(seg_rows))
     else:
         _call('tg_igemm_f32', d, x.ptr, _p(w_oti), (_p(bias) if mobn is None else None), y.ptr, cx.stream)
     if mobn is not None and not fused:
@@ -414,11 +422,16 @@ def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_g
     needs = cx.tape is not None and (x.requires_grad or trains)
     seg_rows = _segs(x, segments)
     nseg = len(seg_rows)
-    sums, zd = cx.zscratch('bn64', 32 * nseg * c)             # 8 replicas x 2 x nseg x c doubles
     mean_inv = cx.scratch('bnmi', 2 * nseg * c)
     y = cx.new_act(x.n, x.h, x.w, c, x.ld, requires_grad=needs)
-    _call('tg_bn_train_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, seg_array(seg_rows), nseg, _p(gamma), _p(beta), eps, decay, _p(mm), _p(mv),
-          _p(sums), zd, _p(mean_inv), cx.stream)
+    if x.bn_sums is not None and x.bn_sums[1] == tuple(seg_rows):
+        sums = x.bn_sums[0]                                   # the producing convolution took the statistics in its epilogue (conv2d(bn_stats=True))
+        _call('tg_bn_train_apply_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, seg_array(seg_rows), nseg, _p(gamma), _p(beta), eps, decay, _p(mm), _p(mv),
+              _p(sums), _p(mean_inv), cx.stream)
+    else:
+        sums, zd = cx.zscratch('bn64', 32 * nseg * c)         # 8 replicas x 2 x nseg x c doubles
+        _call('tg_bn_train_f32', x.ptr, x.ld, y.ptr, y.ld, x.rows, c, seg_array(seg_rows), nseg, _p(gamma), _p(beta), eps, decay, _p(mm), _p(mv),
+              _p(sums), zd, _p(mean_inv), cx.stream)
     if cx.state_replay is not None and mm is not None:
         # this forward pass is being KEPT for a later solver run that TensorFlow would re-execute (Context.sub_tape(replay=...)): the
         # re-execution's only lasting effect is one more moving-statistics update from the same batch sums

@@ -89,7 +89,7 @@ def run_control(variant, k_steps=K):
         T.SUM_REVERSED, T._CHUNK_ELEMS = saved
 
 
-CONTROLS = ('f32a', 'f32b', 'f32c', 'f32d', 'f32e', 'f32f')
+CONTROLS = ('f32a', 'f32b', 'f32c', 'f32d')
 
 
 def controls_path():

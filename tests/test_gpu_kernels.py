@@ -554,3 +554,51 @@ def test_halo_kernel_takes_the_whole_rounds_of_a_launch_and_the_generic_kernel_t
     sums = lambda a: np.frombuffer(a.tobytes(), np.float64)
     np.testing.assert_allclose(sums(outs[0][2]), sums(outs[2][2]), rtol=1e-5, atol=1e-6 * scale * max(segs) * hw * hw)
     np.testing.assert_allclose(sums(outs[0][4]), sums(outs[2][4]), rtol=1e-5, atol=1e-6 * scale_g * max(segs) * hw * hw)
+
+
+@pytest.mark.parametrize("prec", ['f32', 'bf16'])
+@pytest.mark.parametrize("n,hw,ci,co,segs,act", [(6, 16, 128, 128, [2, 4], 'lrelu'),      # the halo-tiled kernel (policy 1)
+                                                 (5, 8, 256, 512, [3, 2], 'lrelu'),        # generic kernel, 8x8 images (cut tiles: fix-up epilogue)
+                                                 (7, 6, 64, 96, [3, 4], 'relu'),           # application boundary inside a tile, overhanging rows
+                                                 (4, 8, 64, 64, [4], None)])
+def test_batch_norm_statistics_in_the_convolution_epilogue(prec, n, hw, ci, co, segs, act):
+    """tg_igemm_bnstat_* + tg_bn_train_apply_f32 against tg_igemm_* + tg_bn_train_f32 (conv -> leaky relu -> batch norm of the SVHN / MNIST
+    classifier, Model/Good_GAN.py:249-350): same stored activation, same normalised output, same moving statistics."""
+    lib = _lib()
+    from tg import geom
+    rng = np.random.default_rng(21)
+    x = torch.from_numpy(rng.standard_normal((n, hw, hw, ci)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((co, 9, ci)) * 0.05).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rng.standard_normal(co).astype(np.float32)).cuda()
+    gamma, beta = torch.from_numpy(rng.standard_normal(co).astype(np.float32)).cuda(), torch.from_numpy(rng.standard_normal(co).astype(np.float32)).cuda()
+    d = geom.conv_fwd(n, hw, hw, ci, co, 3, 1, 'SAME', act=act)
+    rows = n * hw * hw
+    seg_rows = [s * hw * hw for s in segs]
+    sa = (C.c_int32 * len(segs))(*seg_rows)
+    was = lib.call('tg_conv3x3_policy', 1)
+    try:
+        out = {}
+        for mode in ('plain', 'fused'):
+            y = torch.full((n, hw, hw, co), 7.0, device='cuda')
+            z = torch.full((n, hw, hw, co), 7.0, device='cuda')
+            sums = torch.full((32 * len(segs) * co,), 7.0, device='cuda')          # garbage: both paths clear what they use
+            mi = torch.zeros(2 * len(segs) * co, device='cuda')
+            mm, mv = torch.zeros(co, device='cuda'), torch.ones(co, device='cuda')
+            if mode == 'plain':
+                lib.call_igemm('tg_igemm_' + prec, d, lib.ptr(x), lib.ptr(w), lib.ptr(bias), lib.ptr(y), st())
+                lib.call('tg_bn_train_f32', lib.ptr(y), co, lib.ptr(z), co, rows, co, sa, len(segs), lib.ptr(gamma), lib.ptr(beta), 1e-5, 0.9, lib.ptr(mm),
+                         lib.ptr(mv), lib.ptr(sums), 0, lib.ptr(mi), st())
+            else:
+                lib.call_igemm('tg_igemm_bnstat_' + prec, d, lib.ptr(x), lib.ptr(w), lib.ptr(bias), lib.ptr(y), sa, len(segs), lib.ptr(sums), 0, st())
+                lib.call('tg_bn_train_apply_f32', lib.ptr(y), co, lib.ptr(z), co, rows, co, sa, len(segs), lib.ptr(gamma), lib.ptr(beta), 1e-5, 0.9,
+                         lib.ptr(mm), lib.ptr(mv), lib.ptr(sums), lib.ptr(mi), st())
+            torch.cuda.synchronize()
+            out[mode] = [t.cpu().numpy().astype(np.float64) for t in (y, z, mi, mm, mv)]
+    finally:
+        lib.call('tg_conv3x3_policy', was)
+    scale = float(x.abs().max() * w.abs().max()) * 9 * ci
+    names = ('conv output', 'normalised output', 'mean / inv-std', 'moving mean', 'moving variance')
+    for nm, a, b in zip(names, out['fused'], out['plain']):
+        tol = 3e-5 * scale if nm == 'conv output' else 2e-4 * max(1.0, np.abs(b).max())
+        assert np.abs(a - b).max() <= tol, (nm, np.abs(a - b).max(), tol)
+    assert not (out['fused'][1] == 7.0).any()
