@@ -13,8 +13,9 @@ The JSON line also carries
   roofline     — the classifier's 3x3 convolution path (87 % of the step's FLOPs; the north-star kernel path): algorithmic
                  FLOPs of its forward / input-gradient (conv3x3_pipe_kernel, igemm_f32_kernel) and filter-gradient (wgrad3x3_kernel,
                  wgrad_f32_kernel) launches in one iteration / their summed
-                 HIP-event durations, measured in an instrumented eager pass on the launch stream right after the timed
-                 region (the timed region replays hipGraphs, whose inner kernels cannot be bracketed by events);
+                 HIP-event durations, measured in an instrumented eager ONE-STREAM pass right after the timed
+                 region (the timed region overlaps two streams — or replays hipGraphs — where a kernel's events would also
+                 bracket its neighbours);
                  peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).  The figure over ALL igemm / wgrad launches
                  (generator, discriminator, dense, ZCA included) is reported next to it.
   cpu_baseline — the NumPy oracle (oracle/step_cifar10.py, a port: TF1 is not installable) timed on this host's cores:
@@ -96,7 +97,8 @@ def make_config(rank):
         EPOCHS = 1
         TRAIN_SIZE = 56000
         SUMMARY = False
-        USE_HIP_GRAPH = True
+        USE_HIP_GRAPH = None
+        EXEC_MODE = 'auto'
         SEED = 0
         ZCA = synth_zca()
         RANK = rank
@@ -191,7 +193,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=150)      # ~2.4 s timed at 16 ms/step
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying hipGraphs')
+    ap.add_argument('--exec', dest='exec_mode', choices=('auto', 'overlap', 'graph', 'eager'), default='auto',
+                    help="auto: the trainer times overlap and graph in the warm-up iterations and keeps the faster (default); overlap: eager launches "
+                         "with the second-stream overlap; graph: hipGraph replay; eager: one stream")
+    ap.add_argument('--no-graph', action='store_true', help='alias of --exec eager')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--prof-iters', type=int, default=2)
     ap.add_argument('--soak-seconds', type=float, default=8.0,
@@ -218,7 +223,7 @@ def main():
     if torch.cuda.device_count() <= local:
         raise SystemExit("rank %d needs HIP device %d, %d visible" % (rank, local, torch.cuda.device_count()))
     cfg = make_config(rank)
-    cfg.USE_HIP_GRAPH = not args.no_graph
+    cfg.EXEC_MODE = 'eager' if args.no_graph else args.exec_mode
     tr = Train(cfg, None, None)
     tr._build_train_graph(Good_GAN_cifar10)
     if tr.world != args.gpus or tgdist.world_size() != args.gpus or tgdist.rccl_ranks() != args.gpus:
@@ -239,7 +244,9 @@ def main():
         tr.sample_latent()
         tr.train_iteration()
 
-    for i in range(max(args.warmup, 2)):          # >= 2: first call allocates eagerly, second captures the graphs
+    # warm-up: the first call allocates eagerly, graph mode captures in the second; --exec auto decides within 2 * AUTO_TIMED + 4 iterations
+    n_warm = max(args.warmup, 2) if cfg.EXEC_MODE != 'auto' else max(args.warmup, tr.AUTO_ITERS + 1)
+    for i in range(n_warm):
         step(i)
     torch.cuda.synchronize()
     tgdist.barrier()
@@ -266,12 +273,15 @@ def main():
     args.prof_iters = max(args.prof_iters, 1)           # the roofline object needs at least one instrumented pass
     lib.call('tg_prof_reset')
     lib.call('tg_prof_enable', 1)
+    timed_mode = cfg.EXEC_MODE
+    cfg.EXEC_MODE = 'eager'                             # ONE stream: a kernel's HIP events must bracket that kernel alone
     for i in range(args.prof_iters):
         tr.feed(pool[i % len(pool)])
         tr.sample_latent()
         tr.train_iteration(use_graph=False)
     torch.cuda.synchronize()
     lib.call('tg_prof_enable', 0)
+    cfg.EXEC_MODE = timed_mode
     import ctypes as C
     classes = {}
     for cls in range(lib.call('tg_prof_num_classes')):
@@ -366,7 +376,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "CIFAR-10 32x32x3, 4000 labelled, bs=100 fp32 (B_G/L_C/U_C/L_D/U_D=100/50/50/20/80), "
                                    "Good_GAN_cifar10 D+G+C step", "global_batch": SIZES['B_G'] * world, "parallelism": "dp%d" % world,
-                       "hip_graph": bool(cfg.USE_HIP_GRAPH), "algorithmic_gflop_per_step": round(fl['total'] / 1e9, 1),
+                       "exec_mode": cfg.EXEC_MODE, "exec_mode_chosen": tr.exec_mode_chosen()[0] if cfg.EXEC_MODE == 'auto' else cfg.EXEC_MODE,
+                       "exec_mode_timings_ms": {k: round(v * 1e3, 3) for k, v in tr.exec_mode_chosen()[1].items()},
+                       "hip_graph": (tr.exec_mode_chosen()[0] if cfg.EXEC_MODE == 'auto' else cfg.EXEC_MODE) == 'graph', "algorithmic_gflop_per_step": round(fl['total'] / 1e9, 1),
                        "executed_gflop_per_step": round(fl['executed_total'] / 1e9, 1),
                        "step_tflops": round(fl['executed_total'] / (dt / args.steps) / 1e12, 2),
                        "step_tflops_algorithmic": round(fl['total'] / (dt / args.steps) / 1e12, 2), "losses_d_g_c": [round(v, 4) for v in losses]},

@@ -113,14 +113,18 @@ class Train(Train_base):
             # generator is deterministic (no dropout / noise): TF recomputes it in the second sess.run, here the forward
             # pass and its backward closures are kept for _g_forward_backward (bit-identical result, one G forward saved).
             g_replay = []
-            with cx.sub_tape(('good_generator',), replay=g_replay) as g_tape:
-                G = m.good_generator(self.z_g_ph, self.y_g_ph)
+            # (eager launches with the side stream, Context.wgrad_side: the generator's forward pass — small launches — runs beside the
+            # classifier's, which it does not depend on; the two meet where the discriminator's batch is assembled)
+            with cx.wgrad_on_side():
+                with cx.sub_tape(('good_generator',), replay=g_replay) as g_tape:
+                    G = m.good_generator(self.z_g_ph, self.y_g_ph)
             self._g_saved = (G, g_tape, g_replay)
             xz = concat_acts([m.as_image(self.x_u_c_ph), m.as_image(self.x_u_d_ph)])
             if m.zca() is not None:
                 xz = m.zca().apply(xz)
             with cx.rng_scoped('D/C'):
                 c_logits, _ = m.classifier(xz, True, segments=[c.BATCH_SIZE_U_C, c.BATCH_SIZE_U_D])
+            cx.join_wgrad_side()
             oh = ops.argmax_onehot(c_logits, c.NUM_CLASSES)                       # [C_unl_hard | C_unl_d_hard]
             k = c.NUM_CLASSES
             oh_unl = Act(oh[:c.BATCH_SIZE_U_C * k], c.BATCH_SIZE_U_C, 1, 1, k, k)
@@ -264,7 +268,17 @@ class Train(Train_base):
     def train_iteration(self, pre_train=False, use_graph=None):
         """D-update, G-update, C-update on the current placeholder contents (:266-276).  No host sync."""
         cx = self.cx
-        use_graph = getattr(self.config, 'USE_HIP_GRAPH', True) if use_graph is None else use_graph
+        mode = getattr(self.config, 'EXEC_MODE', 'auto')
+        key = 'pre' if pre_train else 'full'
+        if use_graph is None:
+            use_graph = getattr(self.config, 'USE_HIP_GRAPH', None)
+        if mode == 'auto':
+            if use_graph is None and isinstance(cx.rng, PhiloxRNG) and tgdist.graphs_allowed():
+                mode = self._auto_mode(key)               # 'overlap' or 'graph': the measured faster one for this workload on this host
+            else:
+                mode = 'overlap' if not use_graph else 'graph'
+        if use_graph is None:
+            use_graph = mode == 'graph'
         use_graph = use_graph and isinstance(cx.rng, PhiloxRNG)
         if use_graph and not tgdist.graphs_allowed():          # torch's RCCL process group: its watchdog cannot coexist with a capture
             if not getattr(self, '_warned_eager', False) and self.rank == 0:
@@ -273,7 +287,6 @@ class Train(Train_base):
             self._warned_eager = True
             use_graph = False
         segs = self._segments(pre_train)
-        key = 'pre' if pre_train else 'full'
         if self._graphs is None:
             self._graphs = {}
         graphs = self._graphs.setdefault(key, [None] * len(segs))
@@ -282,6 +295,12 @@ class Train(Train_base):
         pending = []
         cx.prep_cache = {}                              # filter layouts stay valid between a network's optimiser steps
         cx.plan_tag = key
+        # second-stream overlap (Context.wgrad_on_side): only beside eager launches — a captured graph with cross-stream edges replays slower
+        # than the single chain on ROCm 7.2 (measured rounds 1 and 3), so graph replay stays one chain
+        side_was = (cx.wgrad_side, cx.wgrad_side_all)
+        if not cx.wgrad_side_env:
+            on = (not use_graph) and mode in ('overlap', 'auto')
+            cx.wgrad_side, cx.wgrad_side_all = on, on
         try:
             for i, (fn, grads, wait) in enumerate(segs):
                 if wait:                                    # this segment opens with an optimiser step: its network's buckets must be in
@@ -299,9 +318,46 @@ class Train(Train_base):
                     pending.append(tgdist.allreduce_sum_async_(grads))
         finally:
             cx.prep_cache = None
+            cx.join_wgrad_side()
+            cx.wgrad_side, cx.wgrad_side_all = side_was
         self._warm = True
         self._warm_keys.add(key)       # graphs of a mode are captured from its SECOND iteration on: the first one allocates its buffers eagerly
         self.iteration += 1
+
+    # ---- EXEC_MODE = 'auto': which way of launching is faster for THIS workload on THIS host is measured, not assumed
+    AUTO_TIMED = 5                     # iterations timed per candidate
+    AUTO_SETTLE = 3                    # untimed iterations in front of each timed block (allocations, lazily loaded code objects, recorded launch plans)
+    AUTO_ITERS = 2 * (AUTO_SETTLE + AUTO_TIMED) + 1
+
+    def _auto_mode(self, key):
+        """Both candidates compute the same numbers; which is faster depends on the workload: the CIFAR-10 / SVHN steps (15 ms of large
+        kernels) gain 2.5 % from the second-stream overlap that only eager launches can have, the MNIST step (2.7 ms in ~300 launches of a
+        few microseconds) is bound by the host's launch rate when launched eagerly (4.1 ms) and needs graph replay.  Schedule per graph
+        key: AUTO_SETTLE untimed + AUTO_TIMED timed iterations with eager launches and the overlap, then the same with graph replay (the
+        first of its untimed ones captures), then the faster one for good.  Costs four device synchronisations in the first AUTO_ITERS
+        iterations, none afterwards."""
+        st = self.__dict__.setdefault('_auto', {}).setdefault(key, dict(n=0, t0=None, t={}, pick=None))
+        if st['pick'] is not None:
+            return st['pick']
+        S, N = self.AUTO_SETTLE, self.AUTO_TIMED
+        n = st['n']
+        st['n'] = n + 1
+        now = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
+        block, k = ('overlap', n) if n < S + N else ('graph', n - (S + N))
+        if n == 2 * (S + N):
+            st['t']['graph'] = (now() - st['t0']) / N
+            st['pick'] = 'overlap' if st['t']['overlap'] <= st['t']['graph'] else 'graph'
+            return st['pick']
+        if block == 'graph' and k == 0:
+            st['t']['overlap'] = (now() - st['t0']) / N
+        if k == S:
+            st['t0'] = now()
+        return block
+
+    def exec_mode_chosen(self, key='full'):
+        """(mode, {candidate: seconds per iteration}) of EXEC_MODE = 'auto' once decided, else (None, partial timings)."""
+        st = getattr(self, '_auto', {}).get(key)
+        return (None, {}) if st is None else (st['pick'], dict(st['t']))
 
     # ---- how much of the gradient exchange is NOT hidden behind the backward pass (bench.py `exchange_exposed_ms`)
     def _mark(self):

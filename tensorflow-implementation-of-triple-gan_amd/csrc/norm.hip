@@ -1106,6 +1106,7 @@ int tg_bn_train_bwd_act_f32(const float* dy, int ld_dy, const float* x, int ld_x
                             float* dbeta, double* dsum, int dsum_zeroed, float* dbias, void* stream) {
   TG_REQUIRE(act == TG_ACT_NONE || act == TG_ACT_RELU || act == TG_ACT_LRELU, "bn_train_bwd_act: activation %d has no derivative from its output here", act);
   TG_REQUIRE((dsum == nullptr) == (dbias == nullptr), "bn_train_bwd_act: dsum / dbias must both be given or both be NULL");
+  TG_REQUIRE(c > 0, "bn_train_bwd_act: c=%d", c);
   const int ncol = c < BN_CW ? c : BN_CW;
   TG_REQUIRE(dsum == nullptr || (c % 4 == 0 && 256 % ((ncol + 3) / 4) == 0 && (c <= BN_CW || c % BN_CW == 0)),
              "bn_train_bwd_act: the bias-gradient sums need 4 | c and column groups that divide 256 (c=%d)", c);

@@ -93,7 +93,7 @@ def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst, wn=None, defer=Tru
     deferred = defer and (cx.tape is not None or cx._phase_depth > 0)
     small = desc.n_img * desc.h_v * desc.w_v * desc.ld_in * desc.c_out * desc.n_taps < (1 << 34)      # < 34 GFLOP: the generic kernel's launches
     wide = ns >= 32 and t * c_dim * n_dim <= 65536
-    if deferred and small and not wide:
+    if deferred and (small or cx.wgrad_side_all) and not wide:
         with cx.wgrad_on_side():                                 # beside the input-gradient chain (Context.wgrad_on_side; joined in flush_tails)
             _call('tg_wgrad_f32', desc, _p(in_act_t), _p(dout_t), _p(slab), ns, cx.stream)
     else:

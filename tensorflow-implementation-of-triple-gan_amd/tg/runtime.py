@@ -294,11 +294,16 @@ class Context(object):
         mode = os.environ.get('TG_SIDE_STREAM', '0')
         self.use_side_stream = mode != '0'
         self.side_forward = mode == '1'
-        # Round 3 experiment, OFF by default (TG_WGRAD_SIDE=1): ONLY the small generic filter-gradient launches of a backward pass on the
-        # side stream (beside the input-gradient chain they do not feed), joined once where their slabs are reduced (flush_tails, see
-        # ops.filter_grad).  MEASURED (one MI355X, bench.py 100 steps): replayed hipGraphs 15.08 -> 15.28 ms per step, eager launches
-        # 15.05 -> 14.94 ms: the cross-stream edges cost a captured graph more than the ~20 overlapped launches give (as in round 1).
-        self.wgrad_side = os.environ.get('TG_WGRAD_SIDE', '0') == '1'
+        # Round 3: second-stream overlap of EAGER launches (config.EXEC_MODE = 'overlap', switched on by Train.train_iteration): every
+        # filter-gradient launch of a backward pass runs on the side stream beside the input-gradient chain it does not feed (joined once
+        # where the slabs are reduced, flush_tails; ops.filter_grad), and the D-update's generator forward beside the classifier's.  The
+        # bandwidth-bound passes of one chain (mean-only-BN centring, pooling, activation gradients) then overlap the matrix kernels of the
+        # other.  MEASURED (one MI355X, bench.py 100 steps, same box): eager one stream 14.96 ms, eager + overlap 14.59 ms; replayed
+        # hipGraphs 14.98 ms, hipGraphs captured WITH the cross-stream edges 15.37 ms — graphs stay a single chain.  TG_WGRAD_SIDE=0/1/2
+        # (off / small launches only / all) overrides for A/B runs.
+        self.wgrad_side_env = 'TG_WGRAD_SIDE' in os.environ                    # set: the environment decides (A/B runs), Train.train_iteration does not
+        self.wgrad_side = os.environ.get('TG_WGRAD_SIDE', '0') in ('1', '2')
+        self.wgrad_side_all = os.environ.get('TG_WGRAD_SIDE', '0') == '2'      # also the large (wgrad3x3) launches
         self._wgrad_side_pending = False
         # fp64 statistics accumulators (fused mean-only BN / batch norm) of one solver run live in ONE arena per phase, zeroed by one
         # launch at the start of the phase instead of one memset per layer and direction (36 -> 3 launches per iteration)

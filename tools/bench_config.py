@@ -65,7 +65,8 @@ def make_config(name='stress64'):
         EPOCHS = 1
         TRAIN_SIZE = 56000
         SUMMARY = False
-        USE_HIP_GRAPH = True
+        USE_HIP_GRAPH = None
+        EXEC_MODE = os.environ.get('TG_EXEC_MODE', 'auto')
         SEED = 0
         MFMA_DTYPE = prec
 
@@ -107,7 +108,7 @@ def main():
         tr.sample_latent()
         tr.train_iteration()
 
-    for _ in range(max(args.warmup, 2)):
+    for _ in range(max(args.warmup, 2) if cfg.EXEC_MODE != 'auto' else max(args.warmup, tr.AUTO_ITERS + 1)):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -121,7 +122,9 @@ def main():
     lib.call('tg_prof_reset')
     lib.call('tg_prof_enable', 1)
     tr.sample_latent()
+    mode_was, cfg.EXEC_MODE = cfg.EXEC_MODE, 'eager'            # one stream: HIP events bracket one kernel
     tr.train_iteration(use_graph=False)
+    cfg.EXEC_MODE = mode_was
     torch.cuda.synchronize()
     lib.call('tg_prof_enable', 0)
     classes = {}
@@ -147,6 +150,8 @@ def main():
                           args.config, cfg.IMAGE_HEIGHT, cfg.IMAGE_WIDTH, cfg.CHANNEL, cfg.BATCH_SIZE_G, cfg.BATCH_SIZE_L_C, cfg.BATCH_SIZE_U_C,
                           cfg.BATCH_SIZE_L_D, cfg.BATCH_SIZE_U_D, Model.__name__, cfg.MFMA_DTYPE),
                       "ms_per_step": round(dt * 1e3, 3), "images_per_sec": round(cfg.BATCH_SIZE_G / dt, 1), "steps": args.steps, "hbm_gib_allocated": round(mem, 2),
+                      "exec_mode": cfg.EXEC_MODE, "exec_mode_chosen": tr.exec_mode_chosen()[0] if cfg.EXEC_MODE == 'auto' else cfg.EXEC_MODE,
+                      "exec_mode_timings_ms": {k: round(v * 1e3, 3) for k, v in tr.exec_mode_chosen()[1].items()},
                       "losses_d_g_c": [round(v, 4) for v in losses], "classes": classes}), flush=True)
 
 
