@@ -74,11 +74,13 @@ bool igemm_pick_tile(const tg_igemm_desc* descs, int n_desc, bool colsum, const 
   for (int i = 0; i < n_desc; ++i) { taps += descs[i].n_taps; max_taps = descs[i].n_taps > max_taps ? descs[i].n_taps : max_taps; }
   int bm = 0, bn = 0;
   double best = 1e300;
+  // TG_IGEMM_TILE (tile audits, tools/tile_audit_step.sh): the named tile wherever it is a candidate, the model's pick elsewhere
+  for (int forced = g_force_bm ? 1 : 0; forced >= 0 && best >= 1e299; --forced)
   for (const Cand& c : cands) {
     // a tile may overhang the last columns (c_out = 544 = 8.5 x 64: nine 64-column tiles instead of seventeen 32-column ones); the
     // quantisation below charges the idle columns
     if (d->c_out % c.bn && c.bn > d->c_out) continue;
-    if (g_force_bm && (c.bm != g_force_bm || c.bn != g_force_bn)) continue;
+    if (forced && (c.bm != g_force_bm || c.bn != g_force_bn)) continue;
     bool seg_ok = true;                                      // COLSUM: a tile may straddle at most one application boundary
     for (int i = 0; colsum && i < nseg; ++i) seg_ok = seg_ok && seg_rows[i] >= c.bm;
     if (!seg_ok) continue;

@@ -275,6 +275,8 @@ class PhiloxRNG(object):
 
 
 class Context(object):
+    _wgrad_side_pending = False                       # launches on the second stream not yet joined (wgrad_on_side)
+
     def __init__(self, device='cuda:0', seed=0):
         lib.load()                                   # fails loudly when the HIP extension is missing
         if not torch.cuda.is_available():
