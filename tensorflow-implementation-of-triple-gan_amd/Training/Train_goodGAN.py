@@ -346,7 +346,10 @@ class Train(Train_base):
         block, k = ('overlap', n) if n < S + N else ('graph', n - (S + N))
         if n == 2 * (S + N):
             st['t']['graph'] = (now() - st['t0']) / N
-            st['pick'] = 'overlap' if st['t']['overlap'] <= st['t']['graph'] else 'graph'
+            # replicas decide together (every rank reaches this point in the same iteration): the slowest rank's time per candidate
+            _, worst = tgdist.minmax_over_ranks([st['t']['overlap'], st['t']['graph']], self.cx.device)
+            st['t_all_ranks'] = dict(overlap=worst[0], graph=worst[1])
+            st['pick'] = 'overlap' if worst[0] <= worst[1] else 'graph'
             return st['pick']
         if block == 'graph' and k == 0:
             st['t']['overlap'] = (now() - st['t0']) / N

@@ -31,7 +31,7 @@ import bench
 from tg import dist as tgdist
 tested = tgdist.self_test(tr.cx.device)                    # the start-up check of an N > 1 bench line
 tr.measure_exposed(True)
-for it in range(3):
+for it in range({iters}):
     tr.feed(S.synth_batch(1000 * rank + it, full))
     tr.sample_latent()
     tr.train_iteration()
@@ -54,7 +54,7 @@ tgdist.barrier()
 Saver({ckpt!r}).restore(tr)
 tr.sample_latent()
 torch.cuda.synchronize()
-out = dict(world=tr.world, rank=rank, sums=sums, losses=tr.losses(), tested=tested, exposed=exposed, identical=identical, broken=broken,
+out = dict(world=tr.world, rank=rank, sums=sums, pick=tr.exec_mode_chosen()[0], losses=tr.losses(), tested=tested, exposed=exposed, identical=identical, broken=broken,
            z=tr.z_g_ph.t.cpu().numpy(), rng_state=tr.cx.rng.state.cpu().numpy(),
            p={{k: st.p.cpu().numpy() for k, st in tr.cx.stores.items()}})
 torch.save(out, {out!r} % rank)
@@ -70,13 +70,18 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("graph", [False, True, None])
 def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, graph):
+    """graph = None: config.EXEC_MODE = 'auto' — both candidates are timed with the collectives in place and the replicas decide together
+    (the slowest rank's time per candidate), so the run goes past the decision point."""
     import torch
+    sys.path.insert(0, os.path.join(ROOT, "tensorflow-implementation-of-triple-gan_amd"))
+    from Training.Train_goodGAN import Train
     port = _free_port()
     out = str(tmp_path / "r%d.pt")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT, graph=graph, out=out, ckpt=str(tmp_path / 'ckpt')))
+    iters = 3 if graph is not None else Train.AUTO_ITERS + 2
+    script.write_text(WORKER.format(root=ROOT, graph=graph, out=out, ckpt=str(tmp_path / 'ckpt'), iters=iters))
     os.makedirs(str(tmp_path / 'ckpt'))
     procs = []
     for rank in range(2):
@@ -87,6 +92,8 @@ def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, graph):
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
     r = [torch.load(out % i, weights_only=False) for i in range(2)]
     assert r[0]['world'] == r[1]['world'] == 2
+    if graph is None:
+        assert r[0]['pick'] == r[1]['pick'] and r[0]['pick'] in ('overlap', 'graph'), (r[0]['pick'], r[1]['pick'])
     # bench.py's N > 1 self-validation on the real trainer: exchange self-test, checksum agreement, exposed exchange time (gloo blocks the
     # host, so every wait is fully exposed: > 0)
     for q in r:

@@ -67,3 +67,37 @@ def test_graph_replay_equals_eager_with_bf16_operands_at_the_benchmark_sizes():
     assert l_e == l_g and all(np.isfinite(v) for l in l_g for v in l)
     for net in p_e:
         np.testing.assert_array_equal(p_e[net], p_g[net])
+
+
+def test_execution_modes_compute_the_same_numbers_and_auto_decides():
+    """config.EXEC_MODE: 'eager' (one stream), 'overlap' (filter gradients and the D-update's generator forward on a second stream),
+    'graph' (hipGraph replay) and 'auto' (times the last two over its first AUTO_ITERS iterations, then keeps the faster one) launch
+    the same kernels on the same operands — bit-identical weights after the decision, and the decision is recorded."""
+    from Training.Train_goodGAN import Train
+    steps = Train.AUTO_ITERS + 2
+    ref = None
+    for mode in ('eager', 'overlap', 'graph', 'auto'):
+        tr = G.fresh_trainer(G.make_config(SMALL, USE_HIP_GRAPH=None, EXEC_MODE=mode, SEED=3))
+        tr.set_hyper(lambda_1=0.3, lambda_2=0.5)
+        full = dict(S.SIZES, **SMALL)
+        losses = []
+        for it in range(steps):
+            tr.feed(S.synth_batch(50 + it, full))
+            tr.sample_latent()
+            tr.train_iteration()
+            losses.append(tr.losses())
+        params = {net: st.p.detach().cpu().numpy().copy() for net, st in tr.cx.stores.items()}
+        used_graphs = tr._graphs is not None and all(h is not None for h in tr._graphs.get('full', [None]))
+        pick, timings = tr.exec_mode_chosen()
+        if mode == 'auto':
+            assert pick in ('overlap', 'graph') and set(timings) == {'overlap', 'graph'} and all(t > 0 for t in timings.values()), (pick, timings)
+            assert used_graphs          # the graph candidate was captured and timed
+        else:
+            assert pick is None
+            assert used_graphs == (mode == 'graph')
+        if ref is None:
+            ref = (losses, params)
+        else:
+            assert losses == ref[0], mode
+            for net in params:
+                np.testing.assert_array_equal(params[net], ref[1][net], err_msg=mode)
