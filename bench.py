@@ -155,7 +155,9 @@ def measured_traffic():
         if not os.path.exists(tfile):
             continue
         rec = json.load(open(tfile))
-        tj = rec['dominant_launch']
+        tj = rec.get('dominant_launch')
+        if tj is None:
+            return None, dict(incomplete='profiles/%s holds no record of the dominant launch: re-run tools/pmc_traffic.sh + tools/make_traffic_json.py' % name)
         want = rec.get('kernel_sources_sha256')
         csrc = os.path.join(PKG, 'csrc')
         import hashlib
@@ -244,8 +246,9 @@ def main():
         tr.sample_latent()
         tr.train_iteration()
 
-    # warm-up: the first call allocates eagerly, graph mode captures in the second; --exec auto decides within 2 * AUTO_TIMED + 4 iterations
-    n_warm = max(args.warmup, 2) if cfg.EXEC_MODE != 'auto' else max(args.warmup, tr.AUTO_ITERS + 1)
+    # warm-up: the first call allocates eagerly, graph mode captures in the second; --exec auto decides within AUTO_ITERS iterations (three
+    # alternating blocks per candidate: the first blocks of a fresh process measure page-ins, not the candidates) and runs a few more
+    n_warm = max(args.warmup, 2) if cfg.EXEC_MODE != 'auto' else max(args.warmup, tr.AUTO_ITERS + 11)
     for i in range(n_warm):
         step(i)
     torch.cuda.synchronize()
@@ -367,7 +370,7 @@ def main():
             "replicas_identical": identical,
             "exchange_exposed_ms": None if exposed_ms is None else round(exposed_ms, 4),
             "steps": args.steps,
-            "warmup": args.warmup,
+            "warmup": args.warmup, "warmup_executed": n_warm,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -378,6 +381,7 @@ def main():
                                    "Good_GAN_cifar10 D+G+C step", "global_batch": SIZES['B_G'] * world, "parallelism": "dp%d" % world,
                        "exec_mode": cfg.EXEC_MODE, "exec_mode_chosen": tr.exec_mode_chosen()[0] if cfg.EXEC_MODE == 'auto' else cfg.EXEC_MODE,
                        "exec_mode_timings_ms": {k: round(v * 1e3, 3) for k, v in tr.exec_mode_chosen()[1].items()},
+                       "exec_mode_blocks_ms": {k: [round(x * 1e3, 2) for x in v] for k, v in getattr(tr, '_auto', {}).get('full', {}).get('t', {}).items()},
                        "hip_graph": (tr.exec_mode_chosen()[0] if cfg.EXEC_MODE == 'auto' else cfg.EXEC_MODE) == 'graph', "algorithmic_gflop_per_step": round(fl['total'] / 1e9, 1),
                        "executed_gflop_per_step": round(fl['executed_total'] / 1e9, 1),
                        "step_tflops": round(fl['executed_total'] / (dt / args.steps) / 1e12, 2),

@@ -325,42 +325,47 @@ class Train(Train_base):
         self.iteration += 1
 
     # ---- EXEC_MODE = 'auto': which way of launching is faster for THIS workload on THIS host is measured, not assumed
-    AUTO_TIMED = 5                     # iterations timed per candidate
+    AUTO_TIMED = 5                     # timed iterations per block
     AUTO_SETTLE = 3                    # untimed iterations in front of each timed block (allocations, lazily loaded code objects, recorded launch plans)
-    AUTO_ITERS = 2 * (AUTO_SETTLE + AUTO_TIMED) + 1
+    AUTO_BLOCKS = 3                    # blocks per candidate, alternating: a candidate's time is its FASTEST block
+    AUTO_ITERS = 2 * AUTO_BLOCKS * (AUTO_SETTLE + AUTO_TIMED) + 1
 
     def _auto_mode(self, key):
         """Both candidates compute the same numbers; which is faster depends on the workload: the CIFAR-10 / SVHN steps (15 ms of large
-        kernels) gain 2.5 % from the second-stream overlap that only eager launches can have, the MNIST step (2.7 ms in ~300 launches of a
-        few microseconds) is bound by the host's launch rate when launched eagerly (4.1 ms) and needs graph replay.  Schedule per graph
-        key: AUTO_SETTLE untimed + AUTO_TIMED timed iterations with eager launches and the overlap, then the same with graph replay (the
-        first of its untimed ones captures), then the faster one for good.  Costs four device synchronisations in the first AUTO_ITERS
-        iterations, none afterwards."""
-        st = self.__dict__.setdefault('_auto', {}).setdefault(key, dict(n=0, t0=None, t={}, pick=None))
+        kernels) gain 2.5 - 4 % from the second-stream overlap that only eager launches can have, the MNIST step (2.7 ms in ~300 launches of
+        a few microseconds) is bound by the host's launch rate when launched eagerly (4.1 ms) and needs graph replay.  Schedule per graph
+        key: AUTO_BLOCKS x [overlap block, graph block], a block = AUTO_SETTLE untimed + AUTO_TIMED timed iterations (the first graph block
+        captures); a candidate's time is its fastest block — the first block of a fresh process on a fresh machine measures page-ins of
+        library code, not the candidate (seen: 28 ms for a 14.6 ms step) — then the faster candidate for good.  Costs two device
+        synchronisations per block in the first AUTO_ITERS iterations, none afterwards."""
+        st = self.__dict__.setdefault('_auto', {}).setdefault(key, dict(n=0, t0=None, t={'overlap': [], 'graph': []}, pick=None))
         if st['pick'] is not None:
             return st['pick']
-        S, N = self.AUTO_SETTLE, self.AUTO_TIMED
+        S, N, B = self.AUTO_SETTLE, self.AUTO_TIMED, self.AUTO_BLOCKS
         n = st['n']
         st['n'] = n + 1
         now = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
-        block, k = ('overlap', n) if n < S + N else ('graph', n - (S + N))
-        if n == 2 * (S + N):
-            st['t']['graph'] = (now() - st['t0']) / N
+        b, k = divmod(n, S + N)
+        mode = 'overlap' if b % 2 == 0 else 'graph'
+        if k == 0 and b > 0:                                # the previous block ends here
+            st['t']['graph' if mode == 'overlap' else 'overlap'].append((now() - st['t0']) / N)
+        if b == 2 * B:
+            best = [min(st['t']['overlap']), min(st['t']['graph'])]
             # replicas decide together (every rank reaches this point in the same iteration): the slowest rank's time per candidate
-            _, worst = tgdist.minmax_over_ranks([st['t']['overlap'], st['t']['graph']], self.cx.device)
-            st['t_all_ranks'] = dict(overlap=worst[0], graph=worst[1])
+            _, worst = tgdist.minmax_over_ranks(best, self.cx.device)
+            st['best'] = dict(overlap=worst[0], graph=worst[1])
             st['pick'] = 'overlap' if worst[0] <= worst[1] else 'graph'
             return st['pick']
-        if block == 'graph' and k == 0:
-            st['t']['overlap'] = (now() - st['t0']) / N
         if k == S:
             st['t0'] = now()
-        return block
+        return mode
 
     def exec_mode_chosen(self, key='full'):
         """(mode, {candidate: seconds per iteration}) of EXEC_MODE = 'auto' once decided, else (None, partial timings)."""
         st = getattr(self, '_auto', {}).get(key)
-        return (None, {}) if st is None else (st['pick'], dict(st['t']))
+        if st is None:
+            return None, {}
+        return st['pick'], (dict(st['best']) if 'best' in st else {k: min(v) for k, v in st['t'].items() if v})
 
     # ---- how much of the gradient exchange is NOT hidden behind the backward pass (bench.py `exchange_exposed_ms`)
     def _mark(self):

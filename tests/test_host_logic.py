@@ -220,3 +220,20 @@ def test_tape_split_at_gradient_bucket_boundary():
     assert cx.backward() is None and log == ['y', 'x']
     cx.tape = None
     cx.grad_bucket_boundary()                               # no tape: no-op
+
+
+def test_bench_reads_the_committed_traffic_record_without_a_gpu(tmp_path, monkeypatch):
+    """bench.measured_traffic(): the committed PMC record gives (bytes, detail) when it was collected for the kernel sources in the tree,
+    (None, reason) when it is stale or incomplete — never an exception (a crash here would cost the round's bench line)."""
+    import json
+    import bench
+    traffic, detail = bench.measured_traffic()
+    assert isinstance(detail, dict)
+    assert traffic is None or traffic > 1e8
+    # an incomplete record (a PMC pass whose kernel names did not match) degrades to null
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    (prof / 'r03_traffic.json').write_text(json.dumps({'kernel_sources_sha256': 'x'}))
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    traffic, detail = bench.measured_traffic()
+    assert traffic is None and 'incomplete' in detail

@@ -36,7 +36,7 @@ def entry(match, wgs, min_write_kb=0):
     keeps the launches of one size (the two passes run the same program, so launch i of the FETCH_SIZE pass is launch i of the
     WRITE_SIZE pass)."""
     for (name, w), v in vals.items():
-        if match in name and w == wgs:
+        if (name.endswith(match) or name.endswith(match[:-1] + ', false>')) and w == wgs:      # trailing defaulted template argument (STAT2 = false)
             fs, ws = v['FETCH_SIZE'], v['WRITE_SIZE']
             keep = [i for i in range(min(len(fs), len(ws))) if ws[i] >= min_write_kb]
             if not keep:
