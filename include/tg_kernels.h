@@ -137,6 +137,17 @@ int tg_igemm_bnstat_f32(const tg_igemm_desc* d, const float* in, const float* w,
 int tg_igemm_bnstat_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, const int32_t* seg_rows, int nseg,
                          double* sums, int sums_zeroed, void* scratch, int64_t scratch_bytes, void* stream);
 
+/* A convolution-shaped launch (in practice: the input gradient of the NEXT convolution) whose output dy is the gradient a training-mode batch
+ * norm's backward pass consumes: the launch of tg_igemm_f32 / _bf16 (no bias, no activation) that ALSO adds that pass's two statistics —
+ * S0 = sum dy and S1 = sum dy * x per (application segment, channel), x = the batch norm's INPUT, same shape and channel stride as `out` — into
+ * replica 0 of `sums`, the [8][nseg][2][c_out] fp64 buffer of tg_bn_train_bwd_f32 (zeroed by the call unless sums_zeroed).  Follow with
+ * tg_bn_train_bwd_f32 / tg_bn_train_bwd_act_f32 and sums_zeroed = 2 ("the sums are given"): its statistics launch over dy and x disappears.
+ * Only valid when this launch is the ONLY contribution to dy.  seg_rows as for tg_igemm_colsum_f32. */
+int tg_igemm_bnbwdstat_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* x, float* out, const int32_t* seg_rows, int nseg,
+                           double* sums, int sums_zeroed, void* scratch, int64_t scratch_bytes, void* stream);
+int tg_igemm_bnbwdstat_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* x, float* out, const int32_t* seg_rows, int nseg,
+                            double* sums, int sums_zeroed, void* scratch, int64_t scratch_bytes, void* stream);
+
 /* filter gradient, split over `n_split` pixel ranges:
  * slab[s][t][c][n] = sum_{p in split s} in[pix(p,t),c] * dout[p,n]   (c < ld_in, n < c_out).
  * `dout` is read through (h_out,w_out,ld_out,os,oo) exactly as tg_igemm_f32 writes `out`.
@@ -343,7 +354,9 @@ int tg_bn_train_apply_f32(const float* x, int ld_x, float* y, int ld_y, int rows
 int tg_bn_moving_update_f32(const double* sums, int rows, int c, const int32_t* seg_rows, int nseg, float decay, float* moving_mean,
                             float* moving_var, void* stream);
 /* its backward: dx = gamma*inv*(dy - mean_s(dy) - xhat*mean_s(dy*xhat)) per segment (masked by x > 0 when relu_input: the gradient is
- * then with respect to the pre-ReLU value), dgamma = sum_s sum dy*xhat, dbeta = sum_s sum dy (both NULL: not wanted). */
+ * then with respect to the pre-ReLU value), dgamma = sum_s sum dy*xhat, dbeta = sum_s sum dy (both NULL: not wanted).
+ * sums_zeroed: 0 = the call clears `sums`, 1 = the caller did, 2 = `sums` already HOLDS S0 = sum dy, S1 = sum dy*x (tg_igemm_bnbwdstat_*):
+ * no statistics launch. */
 int tg_bn_train_bwd_f32(const float* dy, int ld_dy, const float* x, int ld_x, float* dx, int ld_dx, int rows, int c, const int32_t* seg_rows, int nseg,
                         const float* gamma, const float* mean_inv, int relu_input, double* sums, int sums_zeroed, float* dgamma, float* dbeta,
                         void* stream);

@@ -90,7 +90,7 @@ struct ConvParams {
   uint32_t in_bytes, w_bytes, out_bytes;
   const void* wpk;                             // bf16 filter packed as consecutive LDS images (filter_pack_kernel) — conv3x3_pipe_kernel<.., BF16 = true>
   int f32;                                     // 1: exact-fp32 operands (conv3x3_pipe_kernel<..., BF16 = false>)
-  int stat2;                                   // COLSUM launches: 1 = statistics of the ACTIVATED output act(acc + bias): colsum[seg][0][c] += v, colsum[seg][1][c] += v*v (batch norm behind the layer)
+  int stat2;                                   // COLSUM launches: 2 = the output is a gradient dy, colsum[seg][0][c] += dy, colsum[seg][1][c] += dy * ymul (tg_igemm_bnbwdstat_*); 1 = statistics of the ACTIVATED output act(acc + bias): colsum[seg][0][c] += v, colsum[seg][1][c] += v*v (batch norm behind the layer)
 };
 
 int compute_units() {
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ymul ? p.ymul : p.out), 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias ? p.bias : p.w), 0, p.bias ? (uint32_t)p.n_store * 4u : 0u, 0x00020000);
-    const bool ym = COLSUM && p.ymul != nullptr;
+    const bool ym = COLSUM && !STAT2 && p.ymul != nullptr;
     const int wm0 = wave * 64;
     // Which pixel of its 32-pixel fragment lane `col` multiplies.  A ds_read_b128 is served in four groups of 16 lanes ({0-3, 12-15, 20-27},
     // {4-11, 16-19, 28-31} and the same + 32), conflict-free when the 16 halo rows of a group differ mod 16 (128-byte rows, the swizzle
@@ -525,30 +525,55 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
               }
             }
         } else if (STAT2) {
-          // batch norm behind the layer: the stored value is v = act(acc + bias) and the statistics are of v (sum and sum of squares per
-          // application segment and channel: the tf.nn.moments / fused batch-norm pass over the activation disappears)
-          const float slope = p.act == TG_ACT_LRELU ? p.alpha : (p.act == TG_ACT_RELU ? 0.f : 1.f);
-          float bias_v[4], cq[4];
+          float cq[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.stat2 == 2) {
+            // input gradient that a batch norm's backward pass consumes (tg_igemm_bnbwdstat_*): the stored value is the gradient dy itself and
+            // the statistics are that pass's two sums, of dy and of dy * x, x = the batch norm's input read at the output's own addresses
+            // (one (mi, ni) fragment ahead of its use, as the multiplier below)
+            uint32_t xv[2][16];
+            auto xload = [&](int f, int buf) {
+              const int mi = f >> 2, ni = f & 3;
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-            const uint32_t bb = __builtin_amdgcn_raw_buffer_load_b32(rs_b, (uint32_t)(n0 + ni * 32 + col) * 4u, 0, 0);
-            bias_v[ni] = __builtin_bit_cast(float, bb);
-            cq[ni] = 0.f;
-          }
+              for (int r = 0; r < 16; ++r) xv[buf][r] = __builtin_amdgcn_raw_buffer_load_b32(rs_y, lane_off(ni, r), pix_off(mi, r), 0);
+            };
+            xload(0, 0);
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
+            for (int f = 0; f < 8; ++f) {
+              const int mi = f >> 2, ni = f & 3;
+              if (f + 1 < 8) xload(f + 1, (f + 1) & 1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const uint32_t off = pix_off(mi, r);
-#pragma unroll
-              for (int ni = 0; ni < 4; ++ni) {
-                const float x = acc[mi][ni][r] + bias_v[ni];
-                const float v = x > 0.f ? x : slope * x;
+              for (int r = 0; r < 16; ++r) {
+                const float v = acc[mi][ni][r];
                 cs[ni] += v;
-                cq[ni] += v * v;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, lane_off(ni, r), off, 0);
+                cq[ni] += v * __builtin_bit_cast(float, xv[f & 1][r]);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, lane_off(ni, r), pix_off(mi, r), 0);
               }
             }
+          } else {
+            // batch norm behind the layer: the stored value is v = act(acc + bias) and the statistics are of v (sum and sum of squares per
+            // application segment and channel: the tf.nn.moments / fused batch-norm pass over the activation disappears)
+            const float slope = p.act == TG_ACT_LRELU ? p.alpha : (p.act == TG_ACT_RELU ? 0.f : 1.f);
+            float bias_v[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+              const uint32_t bb = __builtin_amdgcn_raw_buffer_load_b32(rs_b, (uint32_t)(n0 + ni * 32 + col) * 4u, 0, 0);
+              bias_v[ni] = __builtin_bit_cast(float, bb);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const uint32_t off = pix_off(mi, r);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                  const float x = acc[mi][ni][r] + bias_v[ni];
+                  const float v = x > 0.f ? x : slope * x;
+                  cs[ni] += v;
+                  cq[ni] += v * v;
+                  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, lane_off(ni, r), off, 0);
+                }
+              }
+          }
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
             const float o = __shfl_xor(cq[ni], 32);

@@ -101,7 +101,8 @@ struct IgemmParams {
   const float* ymul;              // COLSUM variant, optional: out = acc * act'(ymul[same position]) (tg_igemm_actsum_*)
   int ymul_act;
   float ymul_alpha;
-  int stat2;                      // COLSUM variant: 1 = the stored value is v = act(acc + bias) and colsum is [nseg][2][c_out]: sums of v and of v*v
+  int stat2;                      // COLSUM variant: 2 = the stored value is the accumulator (a gradient dy) and colsum is [nseg][2][c_out]: sums of dy and of
+                                  // dy * ymul (a batch norm's backward statistics, tg_igemm_bnbwdstat_*); 1 = the stored value is v = act(acc + bias) and colsum is [nseg][2][c_out]: sums of v and of v*v
                                   // (statistics of a batch norm behind the layer, tg_igemm_bnstat_*)
   int nseg, seg_rows[8];
   // ---- work units (tg::igemm_schedule, geom.cpp).  A unit is one output tile over a K range; tiles whose K range is cut into ks > 1
@@ -448,7 +449,9 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
           tile[(wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * TLD + wn0 + ni * 32 + col] = acc[mi][ni][r];
     __syncthreads();
     constexpr int G4 = BN / 4;                            // 16-B pieces per tile row
-    const bool ym = p.ymul != nullptr;
+    const bool bst = p.stat2 == 2;                        // tg_igemm_bnbwdstat_*: sums of dy and dy * x, x = p.ymul read at the output's addresses
+    const bool ym = p.ymul != nullptr && !bst;
+    float bs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, bq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int i = tid; i < BM * G4; i += 256) {
       const int rl = i / G4, cg = i - rl * G4;
       const uint32_t ro = t_ob[rl];
@@ -456,7 +459,18 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       const uint32_t off = ((ro & OOB_OFF) || n >= d.n_store) ? OOB_OFF : ro + (uint32_t)n * 4u;
       const float4 tv = *reinterpret_cast<const float4*>(tile + rl * TLD + cg * 4);
       float va[4] = {tv.x, tv.y, tv.z, tv.w};
-      if (p.stat2) {  // batch norm behind the layer: bias + activation here, statistics of the result; rows beyond M must stay exact zeros
+      if (bst) {      // this thread's pieces all belong to ONE 4-column group (256 % G4 == 0): the sums stay in registers until the tile is done
+        const u32x4 xb = __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, off, 0, 0);          // masked positions read 0 (and hold acc = 0)
+        const uint32_t x0 = xb.x, x1 = xb.y, x2 = xb.z, x3 = xb.w;       // (a bit_cast straight from a vector element reads element 0: take scalars first)
+        const float xs[4] = {__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1), __builtin_bit_cast(float, x2), __builtin_bit_cast(float, x3)};
+        const float m0_ = rl < bnd ? 1.f : 0.f, m1_ = 1.f - m0_;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pr = va[e] * xs[e];
+          bs[0][e] += m0_ * va[e]; bs[1][e] += m1_ * va[e];
+          bq[0][e] += m0_ * pr;    bq[1][e] += m1_ * pr;
+        }
+      } else if (p.stat2) {  // batch norm behind the layer: bias + activation here, statistics of the result; rows beyond M must stay exact zeros
         const bool live = !(ro & OOB_OFF);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -477,6 +491,36 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       const u32x4 pk = {__builtin_bit_cast(uint32_t, va[0]), __builtin_bit_cast(uint32_t, va[1]), __builtin_bit_cast(uint32_t, va[2]),
                         __builtin_bit_cast(uint32_t, va[3])};
       __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_o, off, 0, 0);
+    }
+    if (bst) {
+      // the tile is dead: the per-thread sums go through its LDS as [sum kind][e][thread], column n0 + 4 cg + e = threads cg, cg + G4, ...
+      __syncthreads();
+      static_assert(16 * 256 <= BM * TLD, "the per-thread sums must fit into the tile");
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tile[(0 * 4 + e) * 256 + tid] = bs[0][e];
+        tile[(1 * 4 + e) * 256 + tid] = bs[1][e];
+        tile[(2 * 4 + e) * 256 + tid] = bq[0][e];
+        tile[(3 * 4 + e) * 256 + tid] = bq[1][e];
+      }
+      __syncthreads();
+      if (tid < BN) {
+        const int n = n0 + tid, cg = tid >> 2, e = tid & 3;
+        float s1 = 0.f, s2 = 0.f, q1 = 0.f, q2 = 0.f;
+        for (int t2 = cg; t2 < 256; t2 += G4) {
+          s1 += tile[(0 * 4 + e) * 256 + t2]; s2 += tile[(1 * 4 + e) * 256 + t2];
+          q1 += tile[(2 * 4 + e) * 256 + t2]; q2 += tile[(3 * 4 + e) * 256 + t2];
+        }
+        if (n < d.n_store) {
+          atomicAdd(p.colsum + ((int64_t)seg * 2) * p.c_out + n, (double)s1);
+          atomicAdd(p.colsum + ((int64_t)seg * 2 + 1) * p.c_out + n, (double)q1);
+          if (two) {
+            atomicAdd(p.colsum + ((int64_t)(seg + 1) * 2) * p.c_out + n, (double)s2);
+            atomicAdd(p.colsum + ((int64_t)(seg + 1) * 2 + 1) * p.c_out + n, (double)q2);
+          }
+        }
+      }
+      return;
     }
     if (ym || p.stat2) __syncthreads();
     // column sums: thread (column c, part q) adds rows q, q + PARTS, ... of its column (masked rows hold exact zeros)
@@ -1113,6 +1157,31 @@ extern "C" int tg_igemm_bnstat_f32(const tg_igemm_desc* d, const float* in, cons
 extern "C" int tg_igemm_bnstat_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, const int32_t* seg_rows, int nseg,
                                     double* sums, int sums_zeroed, void* scratch, int64_t scratch_bytes, void* stream) {
   return igemm_bnstat_impl(d, in, w, bias, out, seg_rows, nseg, sums, sums_zeroed, scratch, scratch_bytes, stream, true);
+}
+
+// input gradient (or any conv) whose output dy is consumed by a batch norm's backward pass: that pass's statistics in the epilogue
+static int igemm_bnbwdstat_impl(const tg_igemm_desc* d, const float* in, const float* w, const float* x, float* out, const int32_t* seg_rows, int nseg,
+                                double* sums, int sums_zeroed, void* scratch, int64_t scratch_bytes, void* stream, bool bf16) {
+  TG_REQUIRE(d && sums && x && seg_rows && nseg >= 1 && nseg <= 8, "igemm_bnbwdstat: bad args");
+  TG_REQUIRE(d->n_group == 0 && d->act == TG_ACT_NONE, "igemm_bnbwdstat: grouped columns / a fused activation are not supported");
+  int tot = 0;
+  for (int i = 0; i < nseg; ++i) { TG_REQUIRE(seg_rows[i] >= 32, "igemm_bnbwdstat: segment %d has %d rows (need at least one 32-row tile)", i, seg_rows[i]); tot += seg_rows[i]; }
+  TG_REQUIRE(tot == d->n_img * d->h_v * d->w_v, "igemm_bnbwdstat: segments sum to %d rows, launch has %d", tot, d->n_img * d->h_v * d->w_v);
+  if (!sums_zeroed) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 8 * 2 * nseg * d->c_out, tg::as_stream(stream));      // all eight replicas of the batch norm's buffer
+    if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn backward statistics)");
+  }
+  return igemm_impl(d, 1, in, w, nullptr, out, stream, sums, seg_rows, nseg, bf16, x, TG_ACT_NONE, 0.f, scratch, scratch_bytes, 2);
+}
+
+extern "C" int tg_igemm_bnbwdstat_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* x, float* out, const int32_t* seg_rows, int nseg,
+                                      double* sums, int sums_zeroed, void* scratch, int64_t scratch_bytes, void* stream) {
+  return igemm_bnbwdstat_impl(d, in, w, x, out, seg_rows, nseg, sums, sums_zeroed, scratch, scratch_bytes, stream, false);
+}
+
+extern "C" int tg_igemm_bnbwdstat_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* x, float* out, const int32_t* seg_rows, int nseg,
+                                       double* sums, int sums_zeroed, void* scratch, int64_t scratch_bytes, void* stream) {
+  return igemm_bnbwdstat_impl(d, in, w, x, out, seg_rows, nseg, sums, sums_zeroed, scratch, scratch_bytes, stream, true);
 }
 
 extern "C" int tg_igemm_actsum_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* yact, int act, float alpha, float* out,

@@ -1125,6 +1125,7 @@ static int bn_train_bwd_impl(const float* dy, int ld_dy, const float* x, int ld_
   const int cp = (c + 3) / 4 * 4;
   TG_REQUIRE(c > 0 && ld_dy % 4 == 0 && ld_x % 4 == 0 && ld_dx % 4 == 0 && cp <= ld_dy && cp <= ld_x && cp <= ld_dx, "bn_train_bwd: c=%d vs ld", c);
   hipStream_t s = tg::as_stream(stream);
+  const bool sums_given = sums_zeroed == 2;               // the launch that produced dy took the statistics in its epilogue (tg_igemm_bnbwdstat_*)
   if (!sums_zeroed) {
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * REPL * 2 * nseg * c, s);
     if (e != hipSuccess) return tg::hip_fail(e, "hipMemsetAsync(bn bwd sums)");
@@ -1136,8 +1137,10 @@ static int bn_train_bwd_impl(const float* dy, int ld_dy, const float* x, int ld_
   tg::ProfScope prof(tg::PC_NORM, 0, 20.0 * rows * c, s);
   int chunk; dim3 grid;
   bn_grid(st, rows, c, &chunk, &grid);
-  hipLaunchKernelGGL(bn_sums<true>, grid, dim3(256), 0, s, dy, ld_dy, x, ld_x, c, st, chunk, sums);
-  TG_CHECK_LAUNCH("bn_sums<bwd>");
+  if (!sums_given) {
+    hipLaunchKernelGGL(bn_sums<true>, grid, dim3(256), 0, s, dy, ld_dy, x, ld_x, c, st, chunk, sums);
+    TG_CHECK_LAUNCH("bn_sums<bwd>");
+  }
   hipLaunchKernelGGL(bn_train_bwd_apply, grid, dim3(256), 0, s, dy, ld_dy, x, ld_x, dx, ld_dx, c, st, chunk, sums, gamma, mean_inv, act, alpha, dgamma, dbeta,
                      dsum);
   TG_CHECK_LAUNCH("bn_train_bwd_apply");

@@ -152,7 +152,7 @@ def igemm_workspace_bytes(name, args):
     seg, nseg = None, 0
     if '_colsum_' in name:
         seg, nseg = args[4], args[5]
-    elif '_bnstat_' in name:
+    elif '_bnstat_' in name or '_bnbwdstat_' in name:
         seg, nseg = args[5], args[6]
     elif '_actsum_' in name:
         seg, nseg = args[7], args[8]

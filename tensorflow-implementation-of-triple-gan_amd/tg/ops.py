@@ -10,10 +10,11 @@ from .runtime import Act, ctx, pad32, seg_array
 
 import os as _os
 _BNSTAT = _os.environ.get('TG_BN_STAT_FUSE', '1') != '0'   # A/B switch: batch-norm statistics taken in the producing convolution's epilogue
+_BNBWDSTAT = _os.environ.get('TG_BN_BWD_STAT_FUSE', '1') != '0'   # A/B switch: batch-norm BACKWARD statistics taken in the epilogue of the launch that produces dy
 _BNACT = _os.environ.get('TG_BN_ACT_FUSE', '1') != '0'      # A/B switch: activation derivative + bias gradient folded into the batch-norm backward pass
 _NARROW = _os.environ.get('TG_NARROW_DECONV', '1') != '0'     # A/B switch of csrc/narrow.hip (the generator's image layer, backward)
 _ACTSUM = _os.environ.get('TG_ACTSUM', '1') != '0'      # A/B switch of the input-gradient + activation-derivative + column-sum fusion
-_MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_igemm_actsum_f32', 'tg_igemm_bnstat_f32', 'tg_wgrad_f32')
+_MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_igemm_actsum_f32', 'tg_igemm_bnstat_f32', 'tg_igemm_bnbwdstat_f32', 'tg_wgrad_f32')
 
 
 def _call(name, *args):
@@ -263,7 +264,19 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
                 _call('tg_igemm_actsum_f32', dlist[0], _p(dpre), _p(w_hwio), x.ptr, ACT[sink[0]], sink[1], gx.ptr, seg_array(sink[2]), nsg,
                       _p(gsum), zd, cx.stream)
                 x.grad_fused = (gsum, 1)
+            elif (_BNBWDSTAT and x.bn_bwd_sink is not None and fresh and len(dlist) == 1 and x.c == ci_p == gx.ld == x.ld
+                  and x.bn_bwd_sink[0].ld == gx.ld and len(x.bn_bwd_sink[1]) <= 8 and sum(x.bn_bwd_sink[1]) == x.rows
+                  and geom.colsum_supported(dlist[0], x.bn_bwd_sink[1])):
+                # x is a training-mode batch norm's output and this launch is the first to write its gradient: the batch norm's backward
+                # statistics (sum dy, sum dy * its input) are taken in this epilogue; batch_norm_train's backward checks that nothing else
+                # contributed before it trusts them
+                bn_in, segs = x.bn_bwd_sink
+                bsums, zdb = cx.zscratch('bnb64', 32 * len(segs) * ci_p)
+                _call('tg_igemm_bnbwdstat_f32', dlist[0], _p(dpre), _p(w_hwio), bn_in.ptr, gx.ptr, seg_array(segs), len(segs), _p(bsums), zdb, cx.stream)
+                x.bn_bwd_sums = (bsums, gx)
             else:
+                if x.bn_bwd_sums is not None:
+                    x.bn_bwd_sums = None                  # a second contribution to that gradient: the sums of the first alone are not the statistics
                 dds = lib.desc_array(dlist)
                 _call('tg_igemm_multi_f32', C.cast(dds, C.c_void_p), len(dds), _p(dpre), _p(w_hwio), None, gx.ptr, cx.stream)
 
@@ -440,13 +453,18 @@ def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_g
                                              cx.stream))
     if not needs:
         return y
+    if x.ld == y.ld and nseg <= 8:
+        y.bn_bwd_sink = (x, tuple(seg_rows))              # see Act.bn_bwd_sink
 
     def bwd():
         gy = y.grad
         assert gy is not None
         want = trains and gamma_grad is not None
         gx = cx.grad_of(x)
-        bsums, zdb = cx.zscratch('bnb64', 32 * nseg * c)
+        if y.bn_bwd_sums is not None and y.bn_bwd_sums[1] is gy:
+            bsums, zdb = y.bn_bwd_sums[0], 2                # the launch that produced gy took the statistics in its epilogue (tg_igemm_bnbwdstat_*)
+        else:
+            bsums, zdb = cx.zscratch('bnb64', 32 * nseg * c)
         sink = x.bias_sink if _BNACT else None
         if sink is not None and x.ld == gx.ld and c % 4 == 0 and (c <= 256 and 256 % (c // 4) == 0 or c % 256 == 0):
             # x = act(conv + bias) of the layer in front (Act.bias_sink): this pass also multiplies by act'(x) and sums the columns — gx IS

@@ -602,3 +602,64 @@ def test_batch_norm_statistics_in_the_convolution_epilogue(prec, n, hw, ci, co, 
         tol = 3e-5 * scale if nm == 'conv output' else 2e-4 * max(1.0, np.abs(b).max())
         assert np.abs(a - b).max() <= tol, (nm, np.abs(a - b).max(), tol)
     assert not (out['fused'][1] == 7.0).any()
+
+
+@pytest.mark.parametrize("prec", ['f32', 'bf16'])
+@pytest.mark.parametrize("n,hw,ci,co,segs,act", [(6, 16, 128, 128, [2, 4], 'lrelu'),      # the halo-tiled kernel (policy 1)
+                                                 (5, 8, 256, 512, [3, 2], 'lrelu'),        # generic kernel, 8x8 images (cut tiles: fix-up epilogue)
+                                                 (7, 6, 64, 96, [3, 4], 'relu'),           # application boundary inside a tile, overhanging rows
+                                                 (9, 16, 128, 256, [9], None)])            # 128-wide tiles of the generic kernel
+def test_batch_norm_backward_statistics_in_the_epilogue_of_the_launch_that_produces_dy(prec, n, hw, ci, co, segs, act):
+    """tg_igemm_bnbwdstat_* + tg_bn_train_bwd_act_f32(sums_zeroed = 2) against tg_igemm_* + tg_bn_train_bwd_act_f32: the launch that
+    writes the gradient dy of a batch norm's output (the next convolution's input gradient: any conv-shaped launch here) also takes
+    sum dy and sum dy * x, and the backward pass that follows skips its statistics launch: same dy, same dx, same dgamma / dbeta / dbias."""
+    lib = _lib()
+    from tg import geom
+    rng = np.random.default_rng(22)
+    g_in = torch.from_numpy(rng.standard_normal((n, hw, hw, ci)).astype(np.float32)).cuda()          # what the launch convolves (dpre of the next layer)
+    w = torch.from_numpy((rng.standard_normal((co, 9, ci)) * 0.05).astype(np.float32)).cuda()
+    xbn = torch.from_numpy(rng.standard_normal((n, hw, hw, co)).astype(np.float32)).cuda()          # the batch norm's input (an activation's output)
+    gamma = torch.from_numpy(rng.standard_normal(co).astype(np.float32)).cuda()
+    d = geom.conv_fwd(n, hw, hw, ci, co, 3, 1, 'SAME')
+    rows = n * hw * hw
+    seg_rows = [s * hw * hw for s in segs]
+    sa = (C.c_int32 * len(segs))(*seg_rows)
+    # mean / inv-std per (segment, channel) as the forward pass leaves them
+    xs = xbn.double().reshape(rows, co)
+    mi = torch.empty(len(segs), 2, co, dtype=torch.float64)
+    r0 = 0
+    for i, r in enumerate(seg_rows):
+        blk = xs[r0:r0 + r]
+        mi[i, 0] = blk.mean(0).cpu()
+        mi[i, 1] = (1.0 / torch.sqrt(blk.var(0, unbiased=False) + 1e-5)).cpu()
+        r0 += r
+    mean_inv = mi.float().reshape(-1).cuda()
+    was = lib.call('tg_conv3x3_policy', 1)
+    try:
+        out = {}
+        for mode in ('plain', 'fused'):
+            dy = torch.full((n, hw, hw, co), 7.0, device='cuda')
+            dx = torch.full((n, hw, hw, co), 7.0, device='cuda')
+            sums = torch.full((32 * len(segs) * co,), 7.0, device='cuda')          # garbage: both paths clear what they use
+            dsum = torch.zeros(16 * co, device='cuda')
+            dgamma, dbeta, dbias = (torch.zeros(co, device='cuda') for _ in range(3))
+            if mode == 'plain':
+                lib.call_igemm('tg_igemm_' + prec, d, lib.ptr(g_in), lib.ptr(w), None, lib.ptr(dy), st())
+                flag = 0
+            else:
+                lib.call_igemm('tg_igemm_bnbwdstat_' + prec, d, lib.ptr(g_in), lib.ptr(w), lib.ptr(xbn), lib.ptr(dy), sa, len(segs), lib.ptr(sums), 0, st())
+                flag = 2
+            with_bias = co <= 256 and 256 % (co // 4) == 0 or co % 256 == 0        # column layouts the fused bias-gradient sums take
+            lib.call('tg_bn_train_bwd_act_f32', lib.ptr(dy), co, lib.ptr(xbn), co, lib.ptr(dx), co, rows, co, sa, len(segs), lib.ptr(gamma), lib.ptr(mean_inv),
+                     lib.ACT[act], 0.2, lib.ptr(sums), flag,
+                     lib.ptr(dgamma), lib.ptr(dbeta), lib.ptr(dsum) if with_bias else None, 0, lib.ptr(dbias) if with_bias else None, st())
+            torch.cuda.synchronize()
+            out[mode] = [t.cpu().numpy().astype(np.float64) for t in (dy, dx, dgamma, dbeta, dbias)]
+    finally:
+        lib.call('tg_conv3x3_policy', was)
+    scale = float(g_in.abs().max() * w.abs().max()) * 9 * ci
+    names = ('dy', 'dx', 'dgamma', 'dbeta', 'dbias')
+    for nm, a, b in zip(names, out['fused'], out['plain']):
+        tol = 3e-5 * scale if nm == 'dy' else 3e-4 * max(1.0, np.abs(b).max())
+        assert np.abs(a - b).max() <= tol, (nm, np.abs(a - b).max(), tol)
+    assert not (out['fused'][1] == 7.0).any()
