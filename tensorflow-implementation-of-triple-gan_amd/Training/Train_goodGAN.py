@@ -406,11 +406,13 @@ class Train(Train_base):
                 if graphs[i] is not None:
                     continue
                 lib.call('tg_graph_begin_capture', cx.stream)
+                cx.capturing = True
                 try:
                     if os.environ.get('TG_DEBUG_CAPTURE_SLEEP'):          # test hook: widen the capture window
                         time.sleep(float(os.environ['TG_DEBUG_CAPTURE_SLEEP']))
                     fn()
                 finally:
+                    cx.capturing = False
                     h = C.c_void_p()
                     lib.call('tg_graph_end_capture', cx.stream, C.byref(h))
                 graphs[i] = h

@@ -277,6 +277,7 @@ class PhiloxRNG(object):
 
 
 class Context(object):
+    capturing = False                                 # a hipGraph capture is open on the launch stream (Train._capture)
     _wgrad_side_pending = False                       # launches on the second stream not yet joined (wgrad_on_side)
 
     def __init__(self, device='cuda:0', seed=0):
@@ -343,9 +344,15 @@ class Context(object):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _event(self, tag):
-        """one persistent event per call site (created in the first, eager iteration; reused inside captures)."""
-        self.counter += 1
-        key = '%s/%s%d' % (self.phase, tag, self.counter)
+        """one persistent event per call site (created in the first, eager iteration; reused inside captures).  Events are numbered BESIDE the
+        buffers' call-site counter, never through it: the two-stream and the single-chain execution modes record different events, and the
+        buffers of a call site must be the same in both (a graph captured after two-stream iterations would otherwise meet every key with
+        another size and re-allocate inside the capture)."""
+        at = (self.phase, self.counter)
+        if getattr(self, '_ev_at', None) != at:
+            self._ev_at, self._ev_k = at, 0
+        self._ev_k += 1
+        key = '%s/%s%d.%d' % (self.phase, tag, self.counter, self._ev_k)
         ev = self._events.get(key)
         if ev is None:
             ev = self._events[key] = torch.cuda.Event()
@@ -392,6 +399,11 @@ class Context(object):
     def ws(self, key, numel, zero=False):
         t = self.buffers.get(key)
         if t is None or t.numel() < numel:
+            if self.capturing:
+                # a graph holds addresses: a buffer born (or re-born) inside a capture means this pass is not the one the eager pass before
+                # it allocated for — replaying it would write through stale pointers
+                raise lib.TgError("buffer %r (%d floats) would be allocated inside a hipGraph capture: the captured pass differs from the "
+                                  "eager pass that preceded it" % (key, int(numel)))
             t = torch.zeros(int(numel), dtype=torch.float32, device=self.device)
             self.buffers[key] = t
         elif zero:

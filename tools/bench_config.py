@@ -114,7 +114,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    t_issue = (time.perf_counter() - t0) / args.steps     # host time to ISSUE an iteration (the queue is drained only below): when this is
+    torch.cuda.synchronize()                              # close to the step time, the step is bound by the host's launch rate
     dt = (time.perf_counter() - t0) / args.steps
     losses = tr.losses()
     assert all(np.isfinite(losses)), losses
@@ -150,7 +151,7 @@ def main():
                           args.config, cfg.IMAGE_HEIGHT, cfg.IMAGE_WIDTH, cfg.CHANNEL, cfg.BATCH_SIZE_G, cfg.BATCH_SIZE_L_C, cfg.BATCH_SIZE_U_C,
                           cfg.BATCH_SIZE_L_D, cfg.BATCH_SIZE_U_D, Model.__name__, cfg.MFMA_DTYPE),
                       "ms_per_step": round(dt * 1e3, 3), "images_per_sec": round(cfg.BATCH_SIZE_G / dt, 1), "steps": args.steps, "hbm_gib_allocated": round(mem, 2),
-                      "exec_mode": cfg.EXEC_MODE, "exec_mode_chosen": tr.exec_mode_chosen()[0] if cfg.EXEC_MODE == 'auto' else cfg.EXEC_MODE,
+                      "host_issue_ms_per_step": round(t_issue * 1e3, 3), "exec_mode": cfg.EXEC_MODE, "exec_mode_chosen": tr.exec_mode_chosen()[0] if cfg.EXEC_MODE == 'auto' else cfg.EXEC_MODE,
                       "exec_mode_timings_ms": {k: round(v * 1e3, 3) for k, v in tr.exec_mode_chosen()[1].items()},
                       "losses_d_g_c": [round(v, 4) for v in losses], "classes": classes}), flush=True)
 
