@@ -350,7 +350,11 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
             dw = kernel_grad if wn is None else cx.scratch('dw', 25 * c_out * c_in)
             if narrow:
                 nws = cx.scratch('nwws', lib.call('tg_deconv5x5s2_narrow_wgrad_workspace_bytes', x.n, x.h, x.w, c_out, ci_p) // 4)
-                _call('tg_deconv5x5s2_narrow_wgrad_f32', _p(dpre), co_p, x.ptr, x.ld, x.n, x.h, x.w, c_out, c_in, ci_p, _p(nws), _p(dw), cx.stream)
+                if wn is None:
+                    with cx.wgrad_on_side():             # a vector-ALU kernel: beside the input-gradient chain like the other filter gradients
+                        _call('tg_deconv5x5s2_narrow_wgrad_f32', _p(dpre), co_p, x.ptr, x.ld, x.n, x.h, x.w, c_out, c_in, ci_p, _p(nws), _p(dw), cx.stream)
+                else:
+                    _call('tg_deconv5x5s2_narrow_wgrad_f32', _p(dpre), co_p, x.ptr, x.ld, x.n, x.h, x.w, c_out, c_in, ci_p, _p(nws), _p(dw), cx.stream)
             elif wn is None:
                 filter_grad(geom.deconv_wgrad(x.n, x.h, x.w, co_p, ci_p), dpre, x.t, 25, c_out, c_in, kernel_grad)
             else:
