@@ -25,10 +25,10 @@ import gpu_common as G
 from tg import dist as tgdist
 from oracle import step_cifar10 as S
 sizes = dict(B_G=8, L_C=4, U_C=4, L_D=2, U_D=6)
-tr = G.fresh_trainer(G.make_config(sizes, USE_HIP_GRAPH=True, SEED=5))
+tr = G.fresh_trainer(G.make_config(sizes, USE_HIP_GRAPH={graph}, SEED=5))
 tr.set_hyper(lambda_1=0.3, lambda_2=0.5)
 full = dict(S.SIZES, **sizes)
-for it in range(4):
+for it in range({iters}):
     tr.feed(S.synth_batch(it, full))
     tr.sample_latent()
     tr.train_iteration()
@@ -37,7 +37,7 @@ tgdist.barrier()
 t = tgdist.max_over_ranks(1.25, tr.cx.device)
 torch.cuda.synchronize()
 backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else ('rccl-direct' if tgdist._direct is not None else None)
-out = dict(active=tgdist.active(), backend=backend, t=t, rccl_ranks=tgdist.rccl_ranks(),
+out = dict(active=tgdist.active(), backend=backend, t=t, rccl_ranks=tgdist.rccl_ranks(), pick=tr.exec_mode_chosen()[0],
            graphs=any(g is not None for g in (tr._graphs or {{}}).get('full', [])),
            losses=tr.losses(), p={{k: st.p.cpu().numpy() for k, st in tr.cx.stores.items()}})
 torch.save(out, {out!r})
@@ -45,11 +45,12 @@ tgdist.shutdown()
 '''
 
 
-def _run(tmp_path, single, backend=None):
+def _run(tmp_path, single, backend=None, graph=True, iters=4):
     import torch
-    out = str(tmp_path / ('single%s.pt' % (backend or '') if single else 'plain.pt'))
-    script = tmp_path / ('w%d%s.py' % (single, backend or ''))
-    script.write_text(WORKER.format(root=ROOT, out=out))
+    tag = '%s%s%d' % (backend or '', graph, iters)
+    out = str(tmp_path / ('single%s.pt' % tag if single else 'plain%s.pt' % tag))
+    script = tmp_path / ('w%d%s.py' % (single, tag))
+    script.write_text(WORKER.format(root=ROOT, out=out, graph=graph, iters=iters))
     for attempt in range(2):
         s = socket.socket()
         s.bind(('127.0.0.1', 0))
@@ -96,6 +97,22 @@ def test_one_replica_direct_rccl_run_is_bit_identical(tmp_path):
     single = _run(tmp_path, True)
     assert single['active'] is True and single['backend'] == 'rccl-direct' and single['graphs'] is True and single['rccl_ranks'] == 1
     assert single['t'] == 1.25
+    assert single['losses'] == plain['losses']
+    for k in plain['p']:
+        np.testing.assert_array_equal(single['p'][k], plain['p'][k], err_msg=k)
+
+
+def test_one_replica_direct_rccl_run_through_the_execution_mode_decision(tmp_path):
+    """config.EXEC_MODE = 'auto' beside the direct RCCL transport: blocks of eager two-stream iterations (filter gradients on the second
+    stream, gradient buckets all-reduced asynchronously on the exchange stream) alternate with blocks of graph replay until the mode is
+    decided across "all" ranks with a max-all-reduce — bit-identical to the plain single-process run in the same mode sequence."""
+    sys.path.insert(0, os.path.join(ROOT, "tensorflow-implementation-of-triple-gan_amd"))
+    from Training.Train_goodGAN import Train
+    iters = Train.AUTO_ITERS + 2
+    plain = _run(tmp_path, False, graph=None, iters=iters)
+    single = _run(tmp_path, True, graph=None, iters=iters)
+    assert single['active'] is True and single['backend'] == 'rccl-direct' and single['graphs'] is True and single['rccl_ranks'] == 1
+    assert single['pick'] in ('overlap', 'graph') and plain['pick'] in ('overlap', 'graph')
     assert single['losses'] == plain['losses']
     for k in plain['p']:
         np.testing.assert_array_equal(single['p'][k], plain['p'][k], err_msg=k)
