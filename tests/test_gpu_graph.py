@@ -101,3 +101,29 @@ def test_execution_modes_compute_the_same_numbers_and_auto_decides():
             assert losses == ref[0], mode
             for net in params:
                 np.testing.assert_array_equal(params[net], ref[1][net], err_msg=mode)
+
+
+def test_no_buffer_is_allocated_once_the_execution_mode_is_decided():
+    """Every buffer of the step is keyed by its call site and allocated in the first eager iterations; the two-stream and the graph mode
+    share those keys (tg/runtime.py Context._event).  At the bench sizes, through the alternating blocks of EXEC_MODE = 'auto' and 30
+    iterations beyond: the number of call-site buffers and the bytes torch holds stay what they were after the first two iterations of
+    each mode."""
+    import torch
+    from Training.Train_goodGAN import Train
+    sizes = dict(S.SIZES)
+    tr = G.fresh_trainer(G.make_config(sizes, USE_HIP_GRAPH=None, EXEC_MODE='auto', SEED=3))
+    tr.set_hyper(lambda_1=0.3, lambda_2=0.5)
+    b = S.synth_batch(50, sizes)
+    settled = None
+    first_graph_block = Train.AUTO_SETTLE + Train.AUTO_TIMED
+    for it in range(Train.AUTO_ITERS + 30):
+        tr.feed(b)
+        tr.sample_latent()
+        tr.train_iteration()
+        if it == first_graph_block + 2:                     # two-stream block done, graphs captured and replayed once
+            torch.cuda.synchronize()
+            settled = (len(tr.cx.buffers), torch.cuda.memory_allocated())
+    torch.cuda.synchronize()
+    assert tr.exec_mode_chosen()[0] in ('overlap', 'graph')
+    assert (len(tr.cx.buffers), torch.cuda.memory_allocated()) == settled
+    assert all(np.isfinite(v) for v in tr.losses())
