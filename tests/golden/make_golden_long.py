@@ -7,13 +7,15 @@ class-prototype task of SURVEY §8d from fixed initial weights, fixed batches an
 1 000-image test split is recorded at the fixture's checkpoints (evaluation mode: pop_mean, no dropout, the always-on input noise
 injected from a fixed seed).
 
-Two fixtures (FIXTURES):
+Fixtures (FIXTURES):
   * 'k300'  — round 2's task (pixel noise 0.25, batches 10/10/10/4/6): the error falls from 90 % to 0 within 75 iterations and stays
               there.  Checkpoints every 5 iterations through the transient, so that a lead or lag is measured in ITERATIONS.
   * 'hard'  — a task whose error does NOT fall to zero: every image is a blend a*proto[y] + (1-a)*proto[y'] with a ~ U(0.5, 1) of its own
               class and a random other one (images near a = 0.5 are genuinely ambiguous) under pixel noise 0.75; the error settles at
               10 - 15 % (tuning runs: 13.5 / 14.3 / 12.3 / 11.5 % at iterations 225 ... 300 with pixel noise 0.75, 7 - 8.5 % with 0.4); the
               last 100 iterations run at 2.5x the batch sizes: +-0.3 pp is checked where a classifier that merely "works" does not pass.
+  * 'ref'   — the 'hard' task with the last 50 iterations at the REFERENCE's batch sizes (100 / 50 / 50 / 20 / 80, the bench configuration: 38 s
+              per float64 iteration of the oracle on 8 cores, which is why only 50), checkpoints every 5 iterations there.
 
 Variants per fixture (VARIANTS) — the SAME run evaluated several ways:
   * 'f64'          — float64 (the golden trajectory),
@@ -45,6 +47,7 @@ from oracle import tf_ops as T  # noqa: E402
 
 SIZES = dict(B_G=10, L_C=10, U_C=10, L_D=4, U_D=6)
 SIZES_LATE = dict(B_G=25, L_C=25, U_C=25, L_D=10, U_D=15)
+SIZES_REF = dict(B_G=100, L_C=50, U_C=50, L_D=20, U_D=80)     # the reference's own batch sizes (Training/Train_goodGAN.py:566-572): BASELINE configs[1]
 HYPER = dict(lr=3e-4, cla_lr=3e-3, beta1=0.5, lambda_1=0.3, lambda_2=0.5)
 N_TEST = 1000
 EVAL_CHUNK = 25         # images per evaluation pass (small arrays stay inside the allocator's heap: 4x faster than 250 here)
@@ -55,6 +58,8 @@ FIXTURES = {
                  evals=sorted(set(range(5, 101, 5)) | set(range(25, 301, 25)))),
     'hard': dict(noise=0.75, mix=0.5, phases=((200, SIZES), (100, SIZES_LATE)),
                  evals=sorted(set(range(25, 301, 25)) | set(range(210, 301, 10)))),
+    'ref': dict(noise=0.75, mix=0.5, phases=((250, SIZES), (50, SIZES_REF)),
+                 evals=sorted(set(range(25, 301, 25)) | set(range(255, 301, 5)))),
 }
 VARIANTS = {
     'f64': dict(dtype=np.float64, reversed=False, chunk=1),
@@ -143,6 +148,11 @@ def run(fixture='k300', variant='f64', k_steps=None, log=None, n_test=N_TEST, ev
         T.SUM_REVERSED, T._CHUNK_ELEMS = saved
     return dict(losses=np.asarray(losses, np.float64), eval_steps=np.asarray([e[0] for e in table]),
                 eval_acc=np.asarray([e[1] for e in table]), logits_final=logits.astype(np.float32))
+
+
+def committed():
+    """the fixtures whose float64 trajectory is in the tree (a fixture is generated variant by variant; the tests take those that are there)."""
+    return [f for f in FIXTURES if os.path.exists(path(f, 'f64'))]
 
 
 def load(fixture):

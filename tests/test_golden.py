@@ -57,7 +57,8 @@ def test_oracle_reproduces_the_long_horizon_prefix():
     float32 controls to float32 accuracy: BLAS kernels differ between hosts); the files' own invariants are checked."""
     import make_golden_long as M
     from oracle import step_cifar10 as S
-    for fixture in M.FIXTURES:
+    assert {'k300', 'hard'} <= set(M.committed())
+    for fixture in M.committed():
         ctl = M.load(fixture)
         assert len(ctl) >= 3, (fixture, sorted(ctl))                      # float64 and at least two float32 controls
         K = M.total_steps(fixture)
