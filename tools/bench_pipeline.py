@@ -87,7 +87,7 @@ def main():
             trn = Train(cfg, None, None)
             trn._build_train_graph(Good_GAN_cifar10)
             trn.set_hyper(3e-4, 3e-3, 0.3, 0.5)
-            for _ in range(3):
+            for _ in range(Train.AUTO_ITERS + 3 if getattr(cfg, 'EXEC_MODE', 'auto') == 'auto' else 3):      # past the execution-mode decision
                 trn.feed(nnio.next()); trn.sample_latent(); trn.train_iteration()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -97,7 +97,8 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             out['train_from_tfrecords'] = dict(images_per_sec=round(steps * 100 / dt, 1), ms_per_step=round(dt / steps * 1e3, 3),
-                                               note='CIFAR-10 config, fp32, hipGraph; every iteration decoded from TFRecord files, copied over PCIe (uint8) and scaled on the device')
+                                               exec_mode_chosen=trn.exec_mode_chosen()[0],
+                                               note='CIFAR-10 config, fp32; every iteration decoded from TFRecord files, copied over PCIe (uint8) and scaled on the device')
     print(json.dumps(out), flush=True)
 
 
