@@ -115,7 +115,7 @@ class Train(Train_base):
             g_replay = []
             # (eager launches with the side stream, Context.wgrad_side: the generator's forward pass — small launches — runs beside the
             # classifier's, which it does not depend on; the two meet where the discriminator's batch is assembled)
-            with cx.wgrad_on_side():
+            with cx.wgrad_on_side('fwd'):
                 with cx.sub_tape(('good_generator',), replay=g_replay) as g_tape:
                     G = m.good_generator(self.z_g_ph, self.y_g_ph)
             self._g_saved = (G, g_tape, g_replay)
@@ -299,7 +299,7 @@ class Train(Train_base):
         # than the single chain on ROCm 7.2 (measured rounds 1 and 3), so graph replay stays one chain
         side_was = (cx.wgrad_side, cx.wgrad_side_all)
         if not cx.wgrad_side_env:
-            on = (not use_graph) and mode in ('overlap', 'auto')
+            on = ((not use_graph) and mode in ('overlap', 'auto')) or cx.side_fwd_only
             cx.wgrad_side, cx.wgrad_side_all = on, on
         try:
             for i, (fn, grads, wait) in enumerate(segs):

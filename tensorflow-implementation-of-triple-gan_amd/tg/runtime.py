@@ -277,6 +277,7 @@ class PhiloxRNG(object):
 
 
 class Context(object):
+    side_fwd_only = os.environ.get('TG_SIDE_FWD_ONLY') == '1'
     capturing = False                                 # a hipGraph capture is open on the launch stream (Train._capture)
     _wgrad_side_pending = False                       # launches on the second stream not yet joined (wgrad_on_side)
 
@@ -645,10 +646,12 @@ class Context(object):
         return self._run_reverse(tape, stop_at_boundary)
 
     @contextlib.contextmanager
-    def wgrad_on_side(self):
+    def wgrad_on_side(self, kind='wgrad'):
         """run the enclosed filter-gradient launch on the side stream, after what the main stream has enqueued so far (its operands are
-        final); the main stream goes on with the input-gradient chain and waits for the side stream in join_wgrad_side()."""
-        if not self.wgrad_side or self._side_depth or not self._phase_depth:
+        final); the main stream goes on with the input-gradient chain and waits for the side stream in join_wgrad_side().
+        kind = 'fwd': a forward chain (the D-update's generator forward).  Context.side_fwd_only (TG_SIDE_FWD_ONLY=1, A/B runs inside
+        captured graphs): only those go to the side stream — two cross-stream edges per iteration instead of one pair per filter gradient."""
+        if not self.wgrad_side or self._side_depth or not self._phase_depth or (self.side_fwd_only and kind != 'fwd'):
             yield
             return
         ev = self._event('m2w')
