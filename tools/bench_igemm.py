@@ -33,7 +33,7 @@ for name, hw, ci, co, k, pad in LAYERS:
     ho = d.h_out
     y = torch.empty(N, ho, ho, co, device='cuda')
     st = lib.cur_stream()
-    ms = timeit(lambda: lib.call("tg_igemm_" + PREC, d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st))
+    ms = timeit(lambda: lib.call_igemm("tg_igemm_" + PREC, d, lib.ptr(x), lib.ptr(w), None, lib.ptr(y), st))
     fl = 2.0 * N * ho * ho * co * k * k * ci
     print("fwd   %-26s %8.3f ms  %7.1f TFLOP/s" % (name, ms, fl / ms / 1e9))
     if os.environ.get('FWD_ONLY'):

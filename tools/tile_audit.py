@@ -1,4 +1,6 @@
-"""Audit of the igemm tile model: every single-problem conv-shaped launch of the bench line (profiles/r01_launches.csv) timed with each
+"""(Round 1-2 tool: TG_IGEMM_TILE is read once at library load since round 3, so the in-process sweep below no longer switches tiles —
+use tools/tile_audit_step.sh, which runs one process per tile.)
+Audit of the igemm tile model: every single-problem conv-shaped launch of the bench line (profiles/r01_launches.csv) timed with each
 tile candidate (TG_IGEMM_TILE) against the model's own pick; prints what a perfect per-shape choice would save per step."""
 import collections, csv, os, re, sys
 import torch
