@@ -288,7 +288,9 @@ class Context(object):
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         # a dedicated non-default stream: hipStream capture is illegal on the legacy null stream
-        self.torch_stream = torch.cuda.Stream(device=self.device)
+        # TG_STREAM_PRIO=1 (A/B): the launch stream above the second stream in the hardware queues' priority
+        prio = os.environ.get('TG_STREAM_PRIO') == '1'
+        self.torch_stream = torch.cuda.Stream(device=self.device, priority=-1) if prio else torch.cuda.Stream(device=self.device)
         torch.cuda.set_stream(self.torch_stream)
         # Optional side stream for the small dependent chains that are off the critical path (weight-norm scale + filter re-layouts
         # ahead of a convolution; slab reduce + weight-norm gradient behind a filter-gradient launch), forked from / joined to the
