@@ -14,7 +14,7 @@ The JSON line also carries
                  FLOPs of its forward / input-gradient (conv3x3_pipe_kernel, igemm_f32_kernel) and filter-gradient (wgrad3x3_kernel,
                  wgrad_f32_kernel) launches in one iteration / their summed
                  HIP-event durations, measured in an instrumented eager ONE-STREAM pass right after the timed
-                 region (the timed region overlaps two streams — or replays hipGraphs — where a kernel's events would also
+                 region (the timed region replays a two-stream launch plan — or hipGraphs — where a kernel's events would also
                  bracket its neighbours);
                  peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).  The figure over ALL igemm / wgrad launches
                  (generator, discriminator, dense, ZCA included) is reported next to it.
@@ -195,9 +195,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=150)      # ~2.4 s timed at 16 ms/step
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--exec', dest='exec_mode', choices=('auto', 'overlap', 'graph', 'eager'), default='auto',
-                    help="auto: the trainer times overlap and graph in the warm-up iterations and keeps the faster (default); overlap: eager launches "
-                         "with the second-stream overlap; graph: hipGraph replay; eager: one stream")
+    ap.add_argument('--exec', dest='exec_mode', choices=('auto', 'plan', 'overlap', 'graph', 'eager'), default=os.environ.get('TG_EXEC_MODE', 'auto'),
+                    help="auto: the trainer times plan and graph in the warm-up iterations and keeps the faster (default; TG_EXEC_MODE in the "
+                         "environment overrides the default, so that a launcher that cannot pass flags can pin the mode); plan: the two-stream "
+                         "launch sequence recorded once and re-issued natively (tg_plan_replay); overlap: the same sequence launched from Python; "
+                         "graph: hipGraph replay; eager: one stream")
     ap.add_argument('--no-graph', action='store_true', help='alias of --exec eager')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--prof-iters', type=int, default=2)
@@ -256,10 +258,12 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_issue = time.perf_counter() - t0              # host time to ISSUE the timed steps (no device wait): the launch path's own cost
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0
     tgdist.barrier()
     dt = tgdist.max_over_ranks(dt_local, cx.device)
+    dt_lo, dt_hi = tgdist.minmax_over_ranks([dt_local], cx.device)       # stragglers show as a gap between the fastest and the slowest rank
     losses = tr.losses()
     identical = replicas_identical(cx.stores, cx.device) if world > 1 else None
     exposed_ms = None
@@ -372,6 +376,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup, "warmup_executed": n_warm,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step_rank_min": round(dt_lo[0] / args.steps * 1e3, 4), "ms_per_step_rank_max": round(dt_hi[0] / args.steps * 1e3, 4),
+            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -292,7 +292,7 @@ class cifar10_ZCA():
             import ctypes as C
             part = cx.scratch('zcap', image.n * splits * self.dim)
             dds = lib.desc_array(geom.dense_fwd_splitk(image.n, self.dim, self.dim, splits))
-            lib.call('tg_igemm_multi_f32', C.cast(dds, C.c_void_p), len(dds), image.ptr, lib.ptr(self.wt), None, lib.ptr(part), None, 0, cx.stream)
+            lib.call('tg_igemm_multi_f32', dds, len(dds), image.ptr, lib.ptr(self.wt), None, lib.ptr(part), None, 0, cx.stream)
             lib.call('tg_splitk_reduce_f32', lib.ptr(part), lib.ptr(self.bias), out.ptr, self.dim, image.n, splits, self.dim, cx.stream)
         else:
             d = geom.dense_fwd(image.n, self.dim, self.dim)

@@ -272,14 +272,18 @@ class Train(Train_base):
         key = 'pre' if pre_train else 'full'
         if use_graph is None:
             use_graph = getattr(self.config, 'USE_HIP_GRAPH', None)
+        replayable = isinstance(cx.rng, PhiloxRNG)        # injected draws (parity tests) are host-fed per iteration: nothing to replay
         if mode == 'auto':
-            if use_graph is None and isinstance(cx.rng, PhiloxRNG) and tgdist.graphs_allowed():
-                mode = self._auto_mode(key)               # 'overlap' or 'graph': the measured faster one for this workload on this host
+            if use_graph is None and replayable and tgdist.graphs_allowed():
+                mode = self._auto_mode(key)               # 'plan' or 'graph': the measured faster one for this workload on this host
+            elif use_graph is None and replayable:
+                mode = 'plan'                             # torch's RCCL process group forbids captures (tg/dist.py): plans are plain launches
             else:
                 mode = 'overlap' if not use_graph else 'graph'
         if use_graph is None:
             use_graph = mode == 'graph'
-        use_graph = use_graph and isinstance(cx.rng, PhiloxRNG)
+        use_graph = use_graph and replayable
+        use_plan = mode == 'plan' and replayable and not use_graph
         if use_graph and not tgdist.graphs_allowed():          # torch's RCCL process group: its watchdog cannot coexist with a capture
             if not getattr(self, '_warned_eager', False) and self.rank == 0:
                 print("tg: backend %r cannot run beside hipGraph capture (tg/dist.py) - launching eagerly; "
@@ -292,14 +296,19 @@ class Train(Train_base):
         graphs = self._graphs.setdefault(key, [None] * len(segs))
         if use_graph and key in self._warm_keys and any(g is None for g in graphs):
             self._capture(segs, graphs, key)
+        plans = self.__dict__.setdefault('_plans', {}).setdefault(key, [None] * len(segs)) if use_plan else None
+        # a segment's plan is recorded while it runs eagerly in the SECOND two-stream iteration of its kind (the first one allocates the
+        # buffers and records the multi-launch plans of the RNG / filter preparation / statistics arena) and replayed from then on
+        plan_ready = use_plan and ('plan', key) in self._warm_keys
         pending = []
         cx.prep_cache = {}                              # filter layouts stay valid between a network's optimiser steps
         cx.plan_tag = key
         # second-stream overlap (Context.wgrad_on_side): only beside eager launches — a captured graph with cross-stream edges replays slower
         # than the single chain on ROCm 7.2 (measured rounds 1 and 3), so graph replay stays one chain
         side_was = (cx.wgrad_side, cx.wgrad_side_all)
+        on = cx.wgrad_side
         if not cx.wgrad_side_env:
-            on = ((not use_graph) and mode in ('overlap', 'auto')) or cx.side_fwd_only
+            on = ((not use_graph) and mode in ('overlap', 'auto', 'plan')) or cx.side_fwd_only
             cx.wgrad_side, cx.wgrad_side_all = on, on
         try:
             for i, (fn, grads, wait) in enumerate(segs):
@@ -312,6 +321,10 @@ class Train(Train_base):
                     pending = []
                 if use_graph and graphs[i] is not None:
                     lib.call('tg_graph_launch', graphs[i], cx.stream)
+                elif use_plan and plans[i] is not None:
+                    plans[i].replay()
+                elif plan_ready:
+                    plans[i] = self._record_plan(fn)
                 else:
                     fn()
                 if grads is not None and tgdist.active():
@@ -322,7 +335,27 @@ class Train(Train_base):
             cx.wgrad_side, cx.wgrad_side_all = side_was
         self._warm = True
         self._warm_keys.add(key)       # graphs of a mode are captured from its SECOND iteration on: the first one allocates its buffers eagerly
+        if on and not use_graph:
+            self._warm_keys.add(('plan', key))       # one two-stream iteration has run: its events and side-stream workspaces exist
         self.iteration += 1
+
+    def _record_plan(self, fn):
+        """run segment `fn` eagerly on the two streams while every launch and event operation is appended to a native launch plan
+        (tg/plan.py, include/tg_plan.h); returns the plan.  Buffers may not be born during the recording (the plan holds addresses), and
+        the stores are frozen like under a captured graph."""
+        from tg.plan import Plan
+        cx = self.cx
+        for st in cx.stores.values():
+            st.frozen = True
+        plan = Plan([cx.torch_stream.cuda_stream, cx.side_stream.cuda_stream])
+        was = cx.capturing
+        cx.capturing = True
+        try:
+            with plan.recording():
+                fn()
+        finally:
+            cx.capturing = was
+        return plan
 
     # ---- EXEC_MODE = 'auto': which way of launching is faster for THIS workload on THIS host is measured, not assumed
     AUTO_TIMED = 5                     # timed iterations per block
@@ -338,7 +371,7 @@ class Train(Train_base):
         captures); a candidate's time is its fastest block — the first block of a fresh process on a fresh machine measures page-ins of
         library code, not the candidate (seen: 28 ms for a 14.6 ms step) — then the faster candidate for good.  Costs two device
         synchronisations per block in the first AUTO_ITERS iterations, none afterwards."""
-        st = self.__dict__.setdefault('_auto', {}).setdefault(key, dict(n=0, t0=None, t={'overlap': [], 'graph': []}, pick=None))
+        st = self.__dict__.setdefault('_auto', {}).setdefault(key, dict(n=0, t0=None, t={'plan': [], 'graph': []}, pick=None))
         if st['pick'] is not None:
             return st['pick']
         S, N, B = self.AUTO_SETTLE, self.AUTO_TIMED, self.AUTO_BLOCKS
@@ -346,15 +379,15 @@ class Train(Train_base):
         st['n'] = n + 1
         now = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
         b, k = divmod(n, S + N)
-        mode = 'overlap' if b % 2 == 0 else 'graph'
+        mode = 'plan' if b % 2 == 0 else 'graph'
         if k == 0 and b > 0:                                # the previous block ends here
-            st['t']['graph' if mode == 'overlap' else 'overlap'].append((now() - st['t0']) / N)
+            st['t']['graph' if mode == 'plan' else 'plan'].append((now() - st['t0']) / N)
         if b == 2 * B:
-            best = [min(st['t']['overlap']), min(st['t']['graph'])]
+            best = [min(st['t']['plan']), min(st['t']['graph'])]
             # replicas decide together (every rank reaches this point in the same iteration): the slowest rank's time per candidate
             _, worst = tgdist.minmax_over_ranks(best, self.cx.device)
-            st['best'] = dict(overlap=worst[0], graph=worst[1])
-            st['pick'] = 'overlap' if worst[0] <= worst[1] else 'graph'
+            st['best'] = dict(plan=worst[0], graph=worst[1])
+            st['pick'] = 'plan' if worst[0] <= worst[1] else 'graph'
             return st['pick']
         if k == S:
             st['t0'] = now()

@@ -50,9 +50,11 @@ class Config(object):
     ## additions of the MI355X build (not in the reference)
     SEED = 0                 # initial weights + Philox stream
     USE_HIP_GRAPH = None     # True: replay the solver runs as captured hipGraphs; False: launch eagerly; None: EXEC_MODE decides
-    EXEC_MODE = 'auto'       # 'auto': times 'overlap' and 'graph' over the first iterations and keeps the faster (Train._auto_mode);
+    EXEC_MODE = 'auto'       # 'auto': times 'plan' and 'graph' over the first iterations and keeps the faster (Train._auto_mode);
                              # 'overlap': eager launches, filter gradients and independent forward passes on a second HIP stream beside the
                              # input-gradient chain (measured fastest on MI355X / ROCm 7.2: 14.6 ms against 15.0 ms per CIFAR-10 step);
+                             # 'plan': that two-stream launch sequence recorded once per solver run and re-issued natively (tg_plan_replay,
+                             # include/tg_plan.h) - no interpreter on the launch path;
                              # 'graph': hipGraph replay (single chain); 'eager': eager launches on one stream
     ZCA = None               # (mean, mat) arrays when DATA_DIR holds no cifar10_zca_*.npy
     MFMA_DTYPE = 'f32'       # 'bf16': conv/deconv/dense operands rounded to bf16 inside the MFMA kernels (fp32 accumulate)

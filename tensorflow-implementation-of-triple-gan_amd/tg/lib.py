@@ -104,6 +104,7 @@ def parse_header(path=HEADER_PATH):
 
 
 _lib = None
+_recorder = None          # a tg.plan.Plan while Plan.recording() is open: every launch that succeeds is also appended to it
 
 
 class TgError(RuntimeError):
@@ -141,6 +142,8 @@ def call(name, *args):
         return rc
     if rc != 0:
         raise TgError("%s failed (%d): %s" % (name, rc, lib.tg_last_error_string().decode()))
+    if _recorder is not None:
+        _recorder.on_call(name, args)
     return rc
 
 

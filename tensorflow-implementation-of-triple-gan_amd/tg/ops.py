@@ -78,7 +78,7 @@ def _run_prep_plan(cx, plan):
             lib.PrepJob(j['kernel'].data_ptr(), j['g'].data_ptr() if j['g'] is not None else None, j['scale'].data_ptr() if j['g'] is not None else None,
                         j['w_hwio'].data_ptr(), j['w_oti'].data_ptr(), j['t'] * j['a_pad'], j['a_pad'], j['t'], j['a'], j['b'], j['a_pad'], j['b_pad'])
             for j in part])
-        lib.call('tg_filter_prep_multi_f32', C.cast(arr, C.c_void_p), len(part), cx.stream)
+        lib.call('tg_filter_prep_multi_f32', arr, len(part), cx.stream)
     for j in todo:
         cx.prep_cache[j['key']] = (j['scale'], j['w_oti'], j['w_hwio'], j['bump'], cx.phase)
 
@@ -278,7 +278,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
                 if x.bn_bwd_sums is not None:
                     x.bn_bwd_sums = None                  # a second contribution to that gradient: the sums of the first alone are not the statistics
                 dds = lib.desc_array(dlist)
-                _call('tg_igemm_multi_f32', C.cast(dds, C.c_void_p), len(dds), _p(dpre), _p(w_hwio), None, gx.ptr, cx.stream)
+                _call('tg_igemm_multi_f32', dds, len(dds), _p(dpre), _p(w_hwio), None, gx.ptr, cx.stream)
 
     cx.record(bwd)
     return y
@@ -322,7 +322,7 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
         _call('tg_igemm_f32', d, x.ptr, _p(w_m), _p(bias), y.ptr, cx.stream)
     else:
         dds = lib.desc_array(geom.deconv_fwd(x.n, x.h, x.w, ci_p, co_p, ld_out=ld_out, n_store=c_out, act=act))
-        _call('tg_igemm_multi_f32', C.cast(dds, C.c_void_p), len(dds), x.ptr, _p(w_pad), _p(bias), y.ptr, cx.stream)
+        _call('tg_igemm_multi_f32', dds, len(dds), x.ptr, _p(w_pad), _p(bias), y.ptr, cx.stream)
     if not (needs_w or needs_x):
         return y
 
@@ -656,7 +656,7 @@ def copy_many(jobs):
     for k in range(0, len(jobs), 16):
         part = jobs[k:k + 16]
         arr = (lib.CopyJob * len(part))(*[lib.CopyJob(s.data_ptr(), d.data_ptr() + 4 * int(off), int(n)) for d, off, s, n in part])
-        _call('tg_copy_multi_f32', C.cast(arr, C.c_void_p), len(part), cx.stream)
+        _call('tg_copy_multi_f32', arr, len(part), cx.stream)
 
 
 def reshape(x, n, h, w, c):

@@ -235,7 +235,7 @@ class PhiloxRNG(object):
 
     def _multi(self, ctx, jobs):
         arr = (lib.RngJob * len(jobs))(*[lib.RngJob(j[0].data_ptr(), j[1], j[2], j[3], j[4], j[5]) for j in jobs])
-        lib.call('tg_rng_multi_f32', C.cast(arr, C.c_void_p), len(jobs), lib.ptr(self.state), ctx.stream)
+        lib.call('tg_rng_multi_f32', arr, len(jobs), lib.ptr(self.state), ctx.stream)
 
     def _draw(self, ctx, name, n, mode, a, b, out=None):
         if out is None:
@@ -361,17 +361,28 @@ class Context(object):
             ev = self._events[key] = torch.cuda.Event()
         return ev
 
+    def _ev_record(self, ev, stream):
+        """hipEventRecord on a torch stream; while a launch plan is being recorded (tg.plan.Plan.recording) the operation is appended to it."""
+        ev.record(stream)
+        if lib._recorder is not None:
+            lib._recorder.add_record(ev, stream.cuda_stream)
+
+    def _ev_wait(self, stream, ev):
+        stream.wait_event(ev)
+        if lib._recorder is not None:
+            lib._recorder.add_wait(stream.cuda_stream, ev)
+
     def _fork_side(self):
         if self.use_side_stream:
             ev = self._event('fork')
-            ev.record(self.torch_stream)
-            self.side_stream.wait_event(ev)
+            self._ev_record(ev, self.torch_stream)
+            self._ev_wait(self.side_stream, ev)
 
     def _join_side(self):
         if self.use_side_stream:
             ev = self._event('join')
-            ev.record(self.side_stream)
-            self.torch_stream.wait_event(ev)
+            self._ev_record(ev, self.side_stream)
+            self._ev_wait(self.torch_stream, ev)
 
     @contextlib.contextmanager
     def on_side(self, after_main=False, forward=False):
@@ -381,8 +392,8 @@ class Context(object):
             return
         if after_main:
             ev = self._event('m2s')
-            ev.record(self.torch_stream)
-            self.side_stream.wait_event(ev)
+            self._ev_record(ev, self.torch_stream)
+            self._ev_wait(self.side_stream, ev)
         self._side_depth += 1
         torch.cuda.set_stream(self.side_stream)
         try:
@@ -395,8 +406,8 @@ class Context(object):
         """the main stream continues only after what the side stream has enqueued so far."""
         if self.use_side_stream and self.side_forward and not self._side_depth and self._phase_depth:
             ev = self._event('s2m')
-            ev.record(self.side_stream)
-            self.torch_stream.wait_event(ev)
+            self._ev_record(ev, self.side_stream)
+            self._ev_wait(self.torch_stream, ev)
 
     # ---- workspace -------------------------------------------------------------------------------
     def ws(self, key, numel, zero=False):
@@ -405,8 +416,8 @@ class Context(object):
             if self.capturing:
                 # a graph holds addresses: a buffer born (or re-born) inside a capture means this pass is not the one the eager pass before
                 # it allocated for — replaying it would write through stale pointers
-                raise lib.TgError("buffer %r (%d floats) would be allocated inside a hipGraph capture: the captured pass differs from the "
-                                  "eager pass that preceded it" % (key, int(numel)))
+                raise lib.TgError("buffer %r (%d floats) would be allocated inside a hipGraph capture / launch-plan recording: the recorded pass "
+                                  "differs from the eager pass that preceded it" % (key, int(numel)))
             t = torch.zeros(int(numel), dtype=torch.float32, device=self.device)
             self.buffers[key] = t
         elif zero:
@@ -657,8 +668,8 @@ class Context(object):
             yield
             return
         ev = self._event('m2w')
-        ev.record(self.torch_stream)
-        self.side_stream.wait_event(ev)
+        self._ev_record(ev, self.torch_stream)
+        self._ev_wait(self.side_stream, ev)
         self._side_depth += 1
         torch.cuda.set_stream(self.side_stream)
         try:
@@ -671,8 +682,8 @@ class Context(object):
     def join_wgrad_side(self):
         if self._wgrad_side_pending:
             ev = self._event('w2m')
-            ev.record(self.side_stream)
-            self.torch_stream.wait_event(ev)
+            self._ev_record(ev, self.side_stream)
+            self._ev_wait(self.torch_stream, ev)
             self._wgrad_side_pending = False
 
     def flush_tails(self):
@@ -685,7 +696,7 @@ class Context(object):
         for k in range(0, len(jobs), 16):
             part = jobs[k:k + 16]
             arr = (lib.WnJob * len(part))(*part)
-            lib.call('tg_filter_grad_tail_multi_f32', C.cast(arr, C.c_void_p), len(part), self.stream)
+            lib.call('tg_filter_grad_tail_multi_f32', arr, len(part), self.stream)
 
 
 class _Boundary(object):

@@ -10,15 +10,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "tg_kernels.h")
 IO_HEADER = os.path.join(ROOT, "include", "tg_io.h")
+PLAN_HEADER = os.path.join(ROOT, "include", "tg_plan.h")
 
 
 def _declared(path):
     text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
-    return set(re.findall(r"\b(tg_\w+)\s*\(", text)) - {"tg_status", "tg_igemm_desc"}
+    return set(re.findall(r"\b(tg_\w+)\s*\(", text)) - {"tg_status", "tg_igemm_desc", "tg_plan_word"}
 
 
 def test_header_is_plain_c():
-    for h in (HEADER, IO_HEADER):
+    for h in (HEADER, IO_HEADER, PLAN_HEADER):
         subprocess.check_call(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", h])
 
 
@@ -37,13 +38,57 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (tg_\w+)", exported))
     io_syms = _declared(IO_HEADER)                           # host-side input pipeline (include/tg_io.h)
     assert len(io_syms) == 11 and not (io_syms & set(sigs))
-    assert exported == set(sigs) | io_syms, exported ^ (set(sigs) | io_syms)       # nothing undeclared is exported either
+    plan_syms = _declared(PLAN_HEADER)                       # launch plans (include/tg_plan.h)
+    assert len(plan_syms) == 10 and not (plan_syms & set(sigs))
+    assert exported == set(sigs) | io_syms | plan_syms, exported ^ (set(sigs) | io_syms | plan_syms)       # nothing undeclared is exported either
 
 
 def test_no_torch_types_in_signatures():
-    for h in (HEADER, IO_HEADER):
+    for h in (HEADER, IO_HEADER, PLAN_HEADER):
         text = open(h).read()
         assert "torch" not in text and "at::" not in text and "#include <hip" not in text
+
+
+def test_launch_plan_recorder_without_gpu():
+    """include/tg_plan.h on the host: every launch entry point of tg_kernels.h (last parameter `void* stream`) has a generated trampoline
+    whose signature string matches the header, the generated file is the one tools/gen_plan_thunks.py renders today, and the recorder
+    rejects what it cannot replay (unknown entry point, wrong arity, a stream that is not the plan's) — no launch is made."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_plan_thunks as gen
+    from tg import lib, plan
+    inc = os.path.join(ROOT, "tensorflow-implementation-of-triple-gan_amd", "csrc", "plan_thunks.inc")
+    assert open(inc).read() == gen.render()
+    sigs = lib.parse_header()
+    launches = gen.launches()
+    assert len(launches) >= 80
+    for name, params in launches:
+        assert name in sigs and len(sigs[name][1]) == len(params) + 1
+        kinds = plan.signature(name)
+        assert kinds == "".join("p" if t.endswith("*") else ("f" if t == "float" else "i") for t, _ in params), name
+    for name in ("tg_version", "tg_igemm_workspace_bytes", "tg_graph_launch", "tg_wgrad_splits", "no_such_entry"):
+        assert plan.signature(name) is None
+    p = plan.Plan([0x1000, 0x2000])
+    seg = (C.c_int32 * 2)(5, 7)
+    p.add_launch("tg_fill_f32", (C.c_void_p(0x10), 1.5, 64, C.c_void_p(0x1000)))
+    p.add_launch("tg_fill_f32", (None, C.c_float(2.0), C.c_int64(64), 0x2000))
+    assert len(p) == 2 and p.launches == 2
+    with pytest.raises(lib.TgError, match="not one of the plan's streams"):
+        p.add_launch("tg_fill_f32", (None, 0.0, 1, C.c_void_p(0x3000)))
+    with pytest.raises(lib.TgError, match="is not a launch entry point"):
+        p.add_launch("tg_version", ())
+    with pytest.raises(lib.TgError, match="called with 2 arguments"):
+        p.add_launch("tg_fill_f32", (None, C.c_void_p(0x1000)))
+    h = lib.load()
+    words = (plan.PlanWord * 3)()
+    assert h.tg_plan_add_launch(p.p, b"tg_fill_f32", words, 2, 0) == -1 and b"takes 3 arguments" in h.tg_last_error_string()
+    assert h.tg_plan_add_launch(p.p, b"tg_nope", words, 3, 0) == -1 and b"not a launch entry point" in h.tg_last_error_string()
+    assert h.tg_plan_add_launch(p.p, b"tg_fill_f32", words, 3, 99) == -1 and b"slot" in h.tg_last_error_string()
+    held = p._hold(seg)                                       # host data is copied: the plan's address, the caller's bytes
+    assert held != C.addressof(seg) and list((C.c_int32 * 2).from_address(held)) == [5, 7] and held % 16 == 0
+    assert len(p) == 2
+    one = (C.c_void_p * 1)(C.c_void_p(0x1000))
+    assert h.tg_plan_replay(p.p, one, 1) == -1 and b"stream slot 1" in h.tg_last_error_string()      # refused before anything is issued
 
 
 def test_version_and_error_string_without_gpu(has_gpu):

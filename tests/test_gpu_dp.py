@@ -93,7 +93,7 @@ def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, graph):
     r = [torch.load(out % i, weights_only=False) for i in range(2)]
     assert r[0]['world'] == r[1]['world'] == 2
     if graph is None:
-        assert r[0]['pick'] == r[1]['pick'] and r[0]['pick'] in ('overlap', 'graph'), (r[0]['pick'], r[1]['pick'])
+        assert r[0]['pick'] == r[1]['pick'] and r[0]['pick'] in ('plan', 'graph'), (r[0]['pick'], r[1]['pick'])
     # bench.py's N > 1 self-validation on the real trainer: exchange self-test, checksum agreement, exposed exchange time (gloo blocks the
     # host, so every wait is fully exposed: > 0)
     for q in r:

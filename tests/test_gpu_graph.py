@@ -12,8 +12,10 @@ pytestmark = pytest.mark.gpu
 SMALL = dict(B_G=16, L_C=8, U_C=8, L_D=4, U_D=12)
 
 
-def run(use_graph, steps=4, sizes=SMALL, **over):
+def run(use_graph, steps=4, sizes=SMALL, _holder=None, **over):
     tr = G.fresh_trainer(G.make_config(sizes, USE_HIP_GRAPH=use_graph, SEED=3, **over))
+    if _holder is not None:
+        _holder['tr'] = tr
     tr.set_hyper(lambda_1=0.3, lambda_2=0.5)
     full = dict(S.SIZES, **sizes)
     losses = []
@@ -69,14 +71,31 @@ def test_graph_replay_equals_eager_with_bf16_operands_at_the_benchmark_sizes():
         np.testing.assert_array_equal(p_e[net], p_g[net])
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_plan_replay_equals_eager_at_the_benchmark_sizes(dtype):
+    """config.EXEC_MODE = 'plan' at BASELINE configs[1] / configs[3] sizes: iteration 0 launches eagerly on two streams, iteration 1 records every
+    segment into a native launch plan (include/tg_plan.h) while it runs, iterations 2.. are tg_plan_replay alone — bit-identical weights
+    and losses to the one-stream eager run, Philox state advancing on the device."""
+    sizes = dict(S.SIZES)
+    l_e, p_e, _ = run(False, 5, sizes, MFMA_DTYPE=dtype)
+    tr_holder = {}
+    l_p, p_p, _ = run(None, 5, sizes, MFMA_DTYPE=dtype, EXEC_MODE='plan', _holder=tr_holder)
+    plans = tr_holder['tr']._plans['full']
+    assert all(p is not None for p in plans) and sum(p.launches for p in plans) > 200, [p and p.launches for p in plans]
+    assert l_e == l_p and all(np.isfinite(v) for l in l_p for v in l)
+    for net in p_e:
+        np.testing.assert_array_equal(p_e[net], p_p[net])
+
+
 def test_execution_modes_compute_the_same_numbers_and_auto_decides():
     """config.EXEC_MODE: 'eager' (one stream), 'overlap' (filter gradients and the D-update's generator forward on a second stream),
-    'graph' (hipGraph replay) and 'auto' (times the last two over its first AUTO_ITERS iterations, then keeps the faster one) launch
+    'plan' (the two-stream launch sequence recorded once and re-issued by tg_plan_replay, include/tg_plan.h), 'graph' (hipGraph replay)
+    and 'auto' (times the last two over its first AUTO_ITERS iterations, then keeps the faster one) launch
     the same kernels on the same operands — bit-identical weights after the decision, and the decision is recorded."""
     from Training.Train_goodGAN import Train
     steps = Train.AUTO_ITERS + 2
     ref = None
-    for mode in ('eager', 'overlap', 'graph', 'auto'):
+    for mode in ('eager', 'overlap', 'plan', 'graph', 'auto'):
         tr = G.fresh_trainer(G.make_config(SMALL, USE_HIP_GRAPH=None, EXEC_MODE=mode, SEED=3))
         tr.set_hyper(lambda_1=0.3, lambda_2=0.5)
         full = dict(S.SIZES, **SMALL)
@@ -90,11 +109,18 @@ def test_execution_modes_compute_the_same_numbers_and_auto_decides():
         used_graphs = tr._graphs is not None and all(h is not None for h in tr._graphs.get('full', [None]))
         pick, timings = tr.exec_mode_chosen()
         if mode == 'auto':
-            assert pick in ('overlap', 'graph') and set(timings) == {'overlap', 'graph'} and all(t > 0 for t in timings.values()), (pick, timings)
+            assert pick in ('plan', 'graph') and set(timings) == {'plan', 'graph'} and all(t > 0 for t in timings.values()), (pick, timings)
             assert used_graphs          # the graph candidate was captured and timed
+            assert all(p is not None for p in tr._plans['full'])          # and so was the plan candidate
         else:
             assert pick is None
             assert used_graphs == (mode == 'graph')
+            if mode == 'plan':          # every segment recorded in the second iteration and replayed natively from the third on
+                plans = tr._plans['full']
+                assert all(p is not None for p in plans) and sum(p.launches for p in plans) > 100, [p and p.launches for p in plans]
+                assert sum(len(p) - p.launches for p in plans) >= 4          # the cross-stream events of the overlap are part of the plans
+            else:
+                assert not getattr(tr, '_plans', {})
         if ref is None:
             ref = (losses, params)
         else:
@@ -124,6 +150,6 @@ def test_no_buffer_is_allocated_once_the_execution_mode_is_decided():
             torch.cuda.synchronize()
             settled = (len(tr.cx.buffers), torch.cuda.memory_allocated())
     torch.cuda.synchronize()
-    assert tr.exec_mode_chosen()[0] in ('overlap', 'graph')
+    assert tr.exec_mode_chosen()[0] in ('plan', 'graph')
     assert (len(tr.cx.buffers), torch.cuda.memory_allocated()) == settled
     assert all(np.isfinite(v) for v in tr.losses())

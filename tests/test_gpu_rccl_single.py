@@ -112,7 +112,7 @@ def test_one_replica_direct_rccl_run_through_the_execution_mode_decision(tmp_pat
     plain = _run(tmp_path, False, graph=None, iters=iters)
     single = _run(tmp_path, True, graph=None, iters=iters)
     assert single['active'] is True and single['backend'] == 'rccl-direct' and single['graphs'] is True and single['rccl_ranks'] == 1
-    assert single['pick'] in ('overlap', 'graph') and plain['pick'] in ('overlap', 'graph')
+    assert single['pick'] in ('plan', 'graph') and plain['pick'] in ('plan', 'graph')
     assert single['losses'] == plain['losses']
     for k in plain['p']:
         np.testing.assert_array_equal(single['p'][k], plain['p'][k], err_msg=k)
