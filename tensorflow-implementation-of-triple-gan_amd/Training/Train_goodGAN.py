@@ -383,11 +383,8 @@ class Train(Train_base):
         if k == 0 and b > 0:                                # the previous block ends here
             st['t']['graph' if mode == 'plan' else 'plan'].append((now() - st['t0']) / N)
         if b == 2 * B:
-            best = [min(st['t']['plan']), min(st['t']['graph'])]
             # replicas decide together (every rank reaches this point in the same iteration): the slowest rank's time per candidate
-            _, worst = tgdist.minmax_over_ranks(best, self.cx.device)
-            st['best'] = dict(plan=worst[0], graph=worst[1])
-            st['pick'] = 'plan' if worst[0] <= worst[1] else 'graph'
+            st['pick'], st['best'] = tgdist.decide_together(dict(plan=min(st['t']['plan']), graph=min(st['t']['graph'])), self.cx.device)
             return st['pick']
         if k == S:
             st['t0'] = now()

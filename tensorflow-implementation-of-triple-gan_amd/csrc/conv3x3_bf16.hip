@@ -764,11 +764,11 @@ int conv3x3_bf16_launch(const tg_igemm_desc* d, const float* in, const float* w,
   TG_REQUIRE(ymul == nullptr || simple(ymul_act), "conv3x3: activation %d of the gradient multiplier is not none / relu / leaky relu", ymul_act);
   p.wpk = nullptr;
   if (bf16) {
-    // the bf16 filter goes global -> LDS by LDS-DMA from a packed copy in CALLER-OWNED scratch (size: tg_igemm_bf16_workspace_bytes);
+    // the bf16 filter goes global -> LDS by LDS-DMA from a packed copy in CALLER-OWNED scratch (size: tg_igemm_workspace_bytes(descs, n_desc, seg_rows, nseg, bf16 = 1));
     // the library allocates nothing, and a launch without the scratch it was told to bring is an error, not a slower kernel
     const int64_t need = pack_bytes(d);
     TG_REQUIRE(scratch != nullptr && scratch_bytes >= need,
-               "conv3x3 (bf16): this launch needs %lld bytes of scratch for the packed filter, got %lld (query tg_igemm_bf16_workspace_bytes)",
+               "conv3x3 (bf16): this launch needs %lld bytes of scratch for the packed filter, got %lld (query tg_igemm_workspace_bytes(..., bf16 = 1))",
                (long long)need, (long long)(scratch ? scratch_bytes : 0));
     TG_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 15) == 0, "conv3x3 (bf16): scratch must be 16-byte aligned");
     p.wpk = scratch;

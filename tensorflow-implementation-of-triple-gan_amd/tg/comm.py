@@ -123,8 +123,9 @@ def exchange_id(world, rank, make_id, key='tg_comm_id', timeout=None):
     rank then connects as a client, exactly as torch's own env:// rendezvous does.  Returns (id bytes, store).
 
     Bounded (TG_RENDEZVOUS_TIMEOUT seconds, default 300): every rank announces itself under '<prefix>/here/<rank>'; when the time is
-    up, rank 0 fails with the list of ranks that never arrived and the other ranks with "rank 0 did not publish" — instead of a
-    communicator initialisation that hangs on a rank that is not there."""
+    up, rank 0 fails with the list of ranks that never arrived and the other ranks with "rank 0 did not publish" / "rank 0 never confirmed
+    the group" (they wait for a 'go' key rank 0 sets once every '<prefix>/here/<r>' is present) — instead of a communicator initialisation
+    that hangs on a rank that is not there."""
     import datetime
     import torch.distributed as dist
     timeout = float(os.environ.get('TG_RENDEZVOUS_TIMEOUT', '300')) if timeout is None else float(timeout)
@@ -142,6 +143,7 @@ def exchange_id(world, rank, make_id, key='tg_comm_id', timeout=None):
     key = '%s/%s' % (prefix, key)
     here = lambda r: '%s/here/%d' % (prefix, r)
     store.set(here(rank), b'1')
+    go = '%s/go' % prefix
     if rank == 0:
         store.set(key, make_id())
         try:
@@ -149,11 +151,21 @@ def exchange_id(world, rank, make_id, key='tg_comm_id', timeout=None):
         except Exception:
             missing = [r for r in range(world) if not store.check([here(r)])]
             raise lib.TgError("rendezvous at %s:%d: rank(s) %s of %d did not arrive within %.0f s" % (addr, port, missing, world, timeout))
+        store.set(go, b'1')                # everyone is here: only now may any rank walk into the communicator initialisation
     try:
         store.wait([key], datetime.timedelta(seconds=timeout))
     except Exception:
         raise lib.TgError("rendezvous at %s:%d: rank 0 did not publish the communicator id within %.0f s (rank %d of %d waiting)"
                           % (addr, port, timeout, rank, world))
+    if rank != 0:
+        # the other ranks wait (bounded) for rank 0's word that ALL ranks arrived — a rank that read the id at once would otherwise sit in
+        # ncclCommInitRank, which has no timeout, waiting for one that never comes
+        try:
+            store.wait([go], datetime.timedelta(seconds=timeout + 5))
+        except Exception:
+            missing = [r for r in range(world) if not store.check([here(r)])]
+            raise lib.TgError("rendezvous at %s:%d: rank 0 never confirmed the group within %.0f s (rank %d of %d waiting; not arrived: %s)"
+                              % (addr, port, timeout, rank, world, missing))
     return store.get(key), store
 
 

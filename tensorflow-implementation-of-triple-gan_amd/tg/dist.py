@@ -191,6 +191,17 @@ def minmax_over_ranks(values, device):
     return [-float(x) for x in t[n:]], [float(x) for x in t[:n]]
 
 
+def decide_together(times, device):
+    """{candidate: seconds on THIS rank} -> (the candidate every replica takes, {candidate: the slowest rank's seconds}): replicas
+    must launch the same way (their collectives interleave with the segments of an iteration), so the choice is made from the
+    max over the ranks of every candidate's time — identical on all ranks by construction — and ties go to the first candidate in
+    `times`' order.  Every rank must call this in the same iteration (one max-all-reduce)."""
+    names = list(times)
+    _, worst = minmax_over_ranks([times[k] for k in names], device)
+    pick = min(range(len(names)), key=lambda i: (worst[i], i))
+    return names[pick], dict(zip(names, worst))
+
+
 def self_test(device, n=4096):
     """Start-up check of the exchange every replica is about to rely on: a sum-all-reduce of a vector holding rank + 1 must give
     world (world + 1) / 2 in every element on every rank, and a broadcast from rank 0 must arrive.  Raises RuntimeError naming what

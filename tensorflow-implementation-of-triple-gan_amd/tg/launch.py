@@ -25,20 +25,20 @@ KFD_NODES = '/sys/class/kfd/kfd/topology/nodes'
 
 def _visible_filter(n, env):
     """apply HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (comma lists of indices or UUIDs; an empty string
-    hides every device, an out-of-range index ends the list — the runtime's rule)."""
+    hides every device, an out-of-range or negative index ends the list — the runtime's rule — and a repeated entry counts once)."""
     for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
         v = env.get(var)
         if v is None:
             continue
-        keep = 0
+        seen = set()
         for tok in [t.strip() for t in v.split(',')] if v.strip() else []:
-            if tok.isdigit():
-                if int(tok) >= n:
+            if tok.lstrip('+-').isdigit():
+                if int(tok) < 0 or int(tok) >= n:     # "-1" (the usual way to hide everything / end the list) and an out-of-range index end it
                     break
-                keep += 1
-            elif tok:                 # a UUID ("GPU-...") names one device
-                keep += 1
-        n = min(n, keep)
+                seen.add(int(tok))                    # a repeated index names the same device again
+            elif tok:                                 # a UUID ("GPU-...") names one device
+                seen.add(tok)
+        n = min(n, len(seen))
     return n
 
 

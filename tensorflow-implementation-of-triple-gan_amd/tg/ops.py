@@ -43,6 +43,15 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _single_consumer(y, gy):
+    """The fused backward paths hand a layer its gradient ALREADY multiplied by act'(y) (Act.grad_is_dpre: a batch norm behind it did; Act.grad_fused:
+    the consumer's input-gradient launch did).  That is only the layer's pre-activation gradient if that consumer was the ONLY writer of the
+    buffer: a second consumer's raw contribution in the same buffer cannot be told apart afterwards — refuse instead of training on it."""
+    if (y.grad_is_dpre or y.grad_fused is not None) and gy.contribs > 1:
+        raise lib.TgError("fused backward: the gradient of a %dx%dx%dx%d activation was written by %d consumers, but one of them already folded "
+                          "the activation derivative into it (TG_BN_ACT_FUSE=0 / TG_ACTSUM=0 run such a topology unfused)" % (y.n, y.h, y.w, y.c, gy.contribs))
+
+
 def _segs(x, segments):
     """per-application image counts -> row counts of the batched activation."""
     if segments is None:
@@ -207,6 +216,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     def bwd():
         gy = y.grad
         assert gy is not None, "conv2d backward: no gradient reached the output"
+        _single_consumer(y, gy)
         if mobn is None and act is None and gy.ld == co_p:
             dpre = gy.t                                   # the loss head already wrote a padded dlogits
             if needs_w and bias_grad is not None:
@@ -303,12 +313,14 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
         if wn is not None:
             scale_a = cx.scratch('wnsa', c_out)
             _call('tg_wn_scale_tab_f32', _p(kernel), _p(wn[0]), 25, c_out, c_in, _p(scale_a), cx.stream)
-        w_tr = cx.scratch('wtr', 25 * ci_p * co_p) if needs_x else None
+        # the 3-channel image layer's backward runs on the vector ALUs straight from the [5,5,Cout,Cin] variable (csrc/narrow.hip): no transposed copy
+        narrow = _NARROW and x.ld == ci_p and bool(lib.call('tg_deconv5x5s2_narrow_supported', x.n, x.h, x.w, c_out, ci_p))
+        w_tr = cx.scratch('wtr', 25 * ci_p * co_p) if (needs_x and not narrow) else None
         if merged:
             d, ng, tapmap = geom.deconv_fwd_merged(x.n, x.h, x.w, ci_p, c_out, ld_out, n_store=c_out, act=act)
             w_m = cx.scratch('wmrg', d.c_out * 9 * ci_p)
             _call('tg_deconv_merge_prep_f32', _p(kernel), _p(scale_a), c_out, c_in, ng, d.c_out, ci_p, (C.c_int32 * 36)(*tapmap), _p(w_m), cx.stream)
-            if needs_x:
+            if w_tr is not None:
                 _call('tg_filter_prep_f32', _p(kernel), None, _p(scale_a), 25, c_out, c_in, co_p, ci_p, None, _p(w_tr), co_p, ci_p * co_p, cx.stream)
         else:
             w_pad = cx.scratch('wpad', 25 * co_p * ci_p)
@@ -329,6 +341,7 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
     def bwd():
         gy = y.grad
         assert gy is not None
+        _single_consumer(y, gy)
         if y.grad_is_dpre and gy.ld == co_p:
             dpre = gy.t
         else:
@@ -345,7 +358,6 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
             if needs_w and bias_grad is not None:
                 colstats(0, dpre, co_p, None, 0, y.rows, c_out, [y.rows], s1=bias_grad)
         # the 3-channel image layer: both gradients on the vector ALUs (csrc/narrow.hip) — the MFMA tiles would pad 3 channels to 32
-        narrow = _NARROW and x.ld == ci_p and bool(lib.call('tg_deconv5x5s2_narrow_supported', x.n, x.h, x.w, c_out, ci_p))
         if needs_w:
             dw = kernel_grad if wn is None else cx.scratch('dw', 25 * c_out * c_in)
             if narrow:
@@ -367,6 +379,7 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
             if narrow and gx.ld >= ci_p:
                 _call('tg_deconv5x5s2_narrow_dgrad_f32', _p(dpre), co_p, _p(kernel), _p(scale_a), x.n, x.h, x.w, c_out, c_in, ci_p, gx.ptr, gx.ld, cx.stream)
             else:
+                assert w_tr is not None, "deconv2d backward: the transposed filter was not prepared (gradient buffer narrower than the input's channel stride)"
                 _call('tg_igemm_f32', geom.deconv_dgrad(x.n, x.h, x.w, ci_p, co_p, ld_out=gx.ld, n_store=ci_p), _p(dpre), _p(w_tr), None,
                       gx.ptr, cx.stream)
 
@@ -465,7 +478,7 @@ def batch_norm_train(x, gamma, beta, mm, mv, eps, decay, gamma_grad=None, beta_g
         assert gy is not None
         want = trains and gamma_grad is not None
         gx = cx.grad_of(x)
-        if y.bn_bwd_sums is not None and y.bn_bwd_sums[1] is gy:
+        if y.bn_bwd_sums is not None and y.bn_bwd_sums[1] is gy and gy.contribs == 1:
             bsums, zdb = y.bn_bwd_sums[0], 2                # the launch that produced gy took the statistics in its epilogue (tg_igemm_bnbwdstat_*)
         else:
             bsums, zdb = cx.zscratch('bnb64', 32 * nseg * c)
@@ -527,6 +540,7 @@ def cond_concat(x, y_onehot_t, ncls):
                 # no copy: x's gradient IS the leading channels of the concatenated gradient (every consumer of an activation
                 # gradient reads it through (pointer, channel stride))
                 x.grad = Act(g.t, x.n, x.h, x.w, x.c, g.ld)
+                x.grad.contribs = 1
             else:
                 gx = cx.grad_of(x)
                 _call('tg_actgrad_f32', g.ptr, g.ld, None, 0, None, 0, 1.0, gx.ptr, gx.ld, x.rows, x.c, 0, 0.0, cx.stream)

@@ -1,6 +1,12 @@
 """GPU parity of the MFMA implicit-GEMM family (tg_igemm_f32 / tg_wgrad_f32) against the
-oracle's conv / transposed-conv / dense, through the C ABI.  fp32 tolerance: the kernel
-accumulates in exact fp32 in a different order than NumPy's BLAS -> |err| <= 2e-5 * sum|a||b| scale."""
+oracle's conv / transposed-conv / dense, through the C ABI.
+
+Tolerance (round 4): element-wise |got - ref| <= TOL * S, ref = the oracle evaluated in FLOAT64 on the same operands, S = the same
+operator applied to the operands' absolute values = the ACTUAL sum |a||b| behind that output (+ |bias|).  fp32 accumulation of K
+random-sign products in any order errs by ~0.6 u * S rms (u = 2^-24), ~3 u * S at the five-sigma tail of a million outputs; TOL = 1e-6
+~ 17 u leaves a factor five.  A kernel that rounds its operands to bf16 misses this bound by two orders of magnitude
+(test_tolerance_tells_fp32_from_bf16_operands and the negative controls inside the layer tests) — the previous max-based bound
+(3e-5 * max|x| * max|w| * K) accepted it."""
 import numpy as np
 import pytest
 import torch
@@ -41,9 +47,24 @@ def padc(x, ld):
     return out
 
 
-def close(a, b, scale):
-    err = np.abs(a - b).max()
-    assert err <= 3e-5 * scale, (err, scale)
+TOL = 1e-6          # of the per-output sum |a||b| (module docstring)
+f8 = lambda a: np.asarray(a, np.float64)
+
+
+def worst(got, ref64, sabs):
+    """max over the outputs of |got - ref| / (TOL * sum|a||b|): <= 1 passes."""
+    err = np.abs(f8(got) - ref64)
+    return float((err / (TOL * f8(sabs) + 1e-30)).max())
+
+
+def close(got, ref64, sabs):
+    r = worst(got, ref64, sabs)
+    assert r <= 1.0, "error is %.2f x the fp32 accumulation bound (TOL %.0e of the per-output sum |a||b|)" % (r, TOL)
+
+
+def rejected(got, ref64, sabs, factor=10.0):
+    """the bound tells `got` from `ref64` with room to spare (negative controls)."""
+    return worst(got, ref64, sabs) > factor
 
 
 # 'bf16': the tg_*_bf16 variants (operands rounded to bfloat16 inside the kernel, fp32 accumulation) against the oracle
@@ -85,9 +106,11 @@ def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad, prec):
     wt = (rng.standard_normal((k, k, cin, cout)) * 0.1).astype(np.float32)
     bias = rng.standard_normal(cout).astype(np.float32)
     ci_p, co_p = geom.pad32(cin), geom.pad32(cout)
-    y_ref = T.lrelu(T.conv2d(q(x), q(wt), (s, s), pad) + bias)
+    y_ref = T.lrelu(T.conv2d(f8(q(x)), f8(q(wt)), (s, s), pad) + f8(bias))
+    y_abs = T.conv2d(np.abs(f8(q(x))), np.abs(f8(q(wt))), (s, s), pad) + np.abs(f8(bias))
+    other = T.bf16_round if prec == 'f32' else (lambda a: a)          # negative control: the oracle on the OTHER operand type
+    y_other = T.lrelu(T.conv2d(f8(other(x)), f8(other(wt)), (s, s), pad) + f8(bias))
     ho, wo = y_ref.shape[1:3]
-    scale = np.abs(x).max() * np.abs(wt).max() * k * k * cin
 
     # forward: OTI weights [co_p][k*k][ci_p]
     w_oti = np.zeros((co_p, k * k, ci_p), np.float32)
@@ -99,12 +122,14 @@ def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad, prec):
     lib.call_igemm("tg_igemm_" + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
     assert lib.call('tg_conv3x3_launches') - halo0 == int(_takes_halo_kernel(prec, h, w, ci_p, co_p, k, s, pad))
     y = yd.cpu().numpy()
-    close(y[..., :cout], y_ref, scale)
+    close(y[..., :cout], y_ref, y_abs)
+    assert rejected(y[..., :cout], y_other, y_abs)          # the bound separates fp32 operands from bf16-rounded ones
     assert (y[..., cout:] == 0).all()
 
     # input gradient: padded HWIO weights [k*k][ci_p][co_p]
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
-    dx_ref = T.conv2d_bwd_input(x.shape, q(wt), q(dy), (s, s), pad)
+    dx_ref = T.conv2d_bwd_input(x.shape, f8(q(wt)), f8(q(dy)), (s, s), pad)
+    dx_abs = T.conv2d_bwd_input(x.shape, np.abs(f8(q(wt))), np.abs(f8(q(dy))), (s, s), pad)
     w_hwio = np.zeros((k * k, ci_p, co_p), np.float32)
     w_hwio[:, :cin, :cout] = wt.reshape(k * k, cin, cout)
     dyd, whd = dev(padc(dy, co_p)), dev(w_hwio)
@@ -116,11 +141,13 @@ def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad, prec):
         lib.call_igemm("tg_igemm_" + prec, dd, lib.ptr(dyd), lib.ptr(whd), None, lib.ptr(dxd), lib.cur_stream())
     assert lib.call('tg_conv3x3_launches') - halo0 == int(_takes_halo_kernel(prec, h, w, co_p, ci_p, k, s, pad))
     dx = dxd.cpu().numpy()
-    close(dx[..., :cin], dx_ref, np.abs(dy).max() * np.abs(wt).max() * k * k * cout)
+    close(dx[..., :cin], dx_ref, dx_abs)
+    assert rejected(dx[..., :cin], T.conv2d_bwd_input(x.shape, f8(other(wt)), f8(other(dy)), (s, s), pad), dx_abs)
     assert (dx[..., cin:] == 0).all()
 
     # filter gradient, 3 pixel splits summed on the host
-    dw_ref = T.conv2d_bwd_filter(q(x), q(dy), wt.shape, (s, s), pad)
+    dw_ref = T.conv2d_bwd_filter(f8(q(x)), f8(q(dy)), wt.shape, (s, s), pad)
+    dw_abs = T.conv2d_bwd_filter(np.abs(f8(q(x))), np.abs(f8(q(dy))), wt.shape, (s, s), pad)
     nsplit = 3
     slab = torch.full((nsplit, k * k, ci_p, co_p), 7.0, device='cuda')
     dw_desc = geom.conv_wgrad(n, h, w, ci_p, co_p, k, s, pad)
@@ -129,7 +156,8 @@ def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, s, pad, prec):
     # csrc/wgrad3x3.hip (activation tile read once for the nine taps): 3x3 / stride 1 / SAME, width 16 / 32 / 64, 128 | output channels
     assert lib.call('tg_conv3x3_launches') - halo0 == int(k == 3 and s == 1 and pad == 'SAME' and w in (16, 32, 64) and co_p % 128 == 0)
     dw = slab.cpu().numpy().sum(0)
-    close(dw[:, :cin, :cout].reshape(wt.shape), dw_ref, np.abs(x).max() * np.abs(dy).max() * n * ho * wo)
+    close(dw[:, :cin, :cout].reshape(wt.shape), dw_ref, dw_abs)
+    assert rejected(dw[:, :cin, :cout].reshape(wt.shape), T.conv2d_bwd_filter(f8(other(x)), f8(other(dy)), wt.shape, (s, s), pad), dw_abs)
     assert (dw[:, cin:, :] == 0).all() and (dw[:, :, cout:] == 0).all()
 
 
@@ -146,7 +174,8 @@ def test_deconv5x5s2_fwd_dgrad_wgrad(n, h, w, cin, cout, prec):
     wt = (rng.standard_normal((5, 5, cout, cin)) * 0.1).astype(np.float32)
     bias = rng.standard_normal(cout).astype(np.float32)
     ci_p, co_p = geom.pad32(cin), geom.pad32(cout)
-    y_ref = np.tanh(T.conv2d_transpose(q(x), q(wt)) + bias)
+    y_ref = np.tanh(T.conv2d_transpose(f8(q(x)), f8(q(wt))) + f8(bias))
+    y_abs = T.conv2d_transpose(np.abs(f8(q(x))), np.abs(f8(q(wt)))) + np.abs(f8(bias)) + 0.5          # + tanhf's own error (<= 2 ulp of a value <= 1)
     w_pad = np.zeros((25, co_p, ci_p), np.float32)
     w_pad[:, :cout, :cin] = wt.reshape(25, cout, cin)
     xd, wd, bd = dev(padc(x, ci_p)), dev(w_pad), dev(padc(bias, co_p))
@@ -154,7 +183,7 @@ def test_deconv5x5s2_fwd_dgrad_wgrad(n, h, w, cin, cout, prec):
     yd = torch.full((n, 2 * h, 2 * w, cout), 7.0, device='cuda')
     for d in geom.deconv_fwd(n, h, w, ci_p, co_p, ld_out=cout, n_store=cout, act='tanh'):
         lib.call_igemm("tg_igemm_" + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(yd), lib.cur_stream())
-    close(yd.cpu().numpy(), y_ref, np.abs(x).max() * np.abs(wt).max() * 9 * cin)
+    close(yd.cpu().numpy(), y_ref, y_abs)
 
     # the same forward as ONE 3x3 problem with (output parity, channel) columns (tg_igemm_desc.n_group) and the merged filter
     import ctypes as C
@@ -165,25 +194,27 @@ def test_deconv5x5s2_fwd_dgrad_wgrad(n, h, w, cin, cout, prec):
     lib.call("tg_deconv_merge_prep_f32", lib.ptr(wraw), None, cout, cin, ng, dm.c_out, ci_p, (C.c_int32 * 36)(*tapmap), lib.ptr(wm), lib.cur_stream())
     ym = torch.full((n, 2 * h, 2 * w, cout), 7.0, device='cuda')
     lib.call_igemm("tg_igemm_" + prec, dm, lib.ptr(xd), lib.ptr(wm), lib.ptr(bd), lib.ptr(ym), lib.cur_stream())
-    close(ym.cpu().numpy(), y_ref, np.abs(x).max() * np.abs(wt).max() * 9 * cin)
+    close(ym.cpu().numpy(), y_ref, y_abs)
 
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
     dyd = dev(padc(dy, co_p))
-    dx_ref = T.conv2d_transpose_bwd_input(q(wt), q(dy))
+    dx_ref = T.conv2d_transpose_bwd_input(f8(q(wt)), f8(q(dy)))
+    dx_abs = T.conv2d_transpose_bwd_input(np.abs(f8(q(wt))), np.abs(f8(q(dy))))
     w_t = np.zeros((25, ci_p, co_p), np.float32)
     w_t[:, :cin, :cout] = wt.reshape(25, cout, cin).transpose(0, 2, 1)
     dxd = torch.full((n, h, w, ci_p), 7.0, device='cuda')
     wtd = dev(w_t)
     lib.call_igemm("tg_igemm_" + prec, geom.deconv_dgrad(n, h, w, ci_p, co_p), lib.ptr(dyd), lib.ptr(wtd), None,
              lib.ptr(dxd), lib.cur_stream())
-    close(dxd.cpu().numpy()[..., :cin], dx_ref, np.abs(dy).max() * np.abs(wt).max() * 25 * cout)
+    close(dxd.cpu().numpy()[..., :cin], dx_ref, dx_abs)
 
-    dw_ref = T.conv2d_transpose_bwd_filter(q(x), q(dy), wt.shape)
+    dw_ref = T.conv2d_transpose_bwd_filter(f8(q(x)), f8(q(dy)), wt.shape)
+    dw_abs = T.conv2d_transpose_bwd_filter(np.abs(f8(q(x))), np.abs(f8(q(dy))), wt.shape)
     slab = torch.full((2, 25, co_p, ci_p), 7.0, device='cuda')
     lib.call("tg_wgrad_" + prec, geom.deconv_wgrad(n, h, w, co_p, ci_p), lib.ptr(dyd), lib.ptr(xd), lib.ptr(slab), 2,
              lib.cur_stream())
     dw = slab.cpu().numpy().sum(0)
-    close(dw[:, :cout, :cin].reshape(wt.shape), dw_ref, np.abs(x).max() * np.abs(dy).max() * n * h * w)
+    close(dw[:, :cout, :cin].reshape(wt.shape), dw_ref, dw_abs)
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -202,7 +233,7 @@ def test_dense_and_identity_layout(prec):
              lib.cur_stream())
     y = yd.cpu().numpy()
     np.testing.assert_array_equal(y[:128], _q(prec, wt).T)                    # exact: one product per output
-    close(y[128:], _q(prec, x[128:]) @ _q(prec, wt).T, np.abs(x).max() * np.abs(wt).max() * kdim)
+    close(y[128:], f8(_q(prec, x[128:])) @ f8(_q(prec, wt)).T, np.abs(f8(_q(prec, x[128:]))) @ np.abs(f8(_q(prec, wt))).T)
 
 
 def test_bad_descriptor_is_rejected():
@@ -294,11 +325,10 @@ def test_cut_long_parities_of_a_transposed_conv_launch(prec):
     y = torch.empty((n, 2 * h, 2 * w, co_p), device='cuda')
     (a, _), (b, _) = _run_both(lib, 'tg_igemm_multi_' + prec, (C.cast(dds, C.c_void_p), len(dds), lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(y),
                                                               lib.cur_stream()), y)
-    y_ref = T.relu(T.conv2d_transpose(q(x), q(wt)) + bias)
-    scale = np.abs(x).max() * np.abs(wt).max() * 9 * cin
-    close(a.cpu().numpy()[..., :cout], y_ref, scale)
-    close(b.cpu().numpy()[..., :cout], y_ref, scale)
-    assert float((a - b).abs().max()) <= 3e-5 * scale
+    y_ref = T.relu(T.conv2d_transpose(f8(q(x)), f8(q(wt))) + f8(bias))
+    y_abs = T.conv2d_transpose(np.abs(f8(q(x))), np.abs(f8(q(wt)))) + np.abs(f8(bias))
+    close(a.cpu().numpy()[..., :cout], y_ref, y_abs)
+    close(b.cpu().numpy()[..., :cout], y_ref, y_abs)
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -358,11 +388,12 @@ def test_narrow_transposed_conv_backward_on_the_vector_alus(n, h, w, cin, cout):
                  lib.ptr(dxd), ci_p, st)
         dx = dxd.cpu().numpy()
         w_eff = wt if sc is None else wt * sc[None, None, :, None]
-        close(dx[..., :cin], T.conv2d_transpose_bwd_input(w_eff, dy), np.abs(dy).max() * np.abs(w_eff).max() * 25 * cout)
+        close(dx[..., :cin], T.conv2d_transpose_bwd_input(f8(w_eff), f8(dy)), T.conv2d_transpose_bwd_input(np.abs(f8(w_eff)), np.abs(f8(dy))))
         assert (dx[..., cin:] == 0).all()
     # filter gradient straight into the [5,5,Cout,Cin] variable's layout
     need = lib.call('tg_deconv5x5s2_narrow_wgrad_workspace_bytes', n, h, w, cout, ci_p)
     ws = torch.empty(need // 4, device='cuda')
     dwd = torch.full((25, cout, cin), 7.0, device='cuda')
     lib.call('tg_deconv5x5s2_narrow_wgrad_f32', lib.ptr(dyd), co_p, lib.ptr(xd), ci_p, n, h, w, cout, cin, ci_p, lib.ptr(ws), lib.ptr(dwd), st)
-    close(dwd.cpu().numpy().reshape(wt.shape), T.conv2d_transpose_bwd_filter(x, dy, wt.shape), np.abs(x).max() * np.abs(dy).max() * n * h * w)
+    close(dwd.cpu().numpy().reshape(wt.shape), T.conv2d_transpose_bwd_filter(f8(x), f8(dy), wt.shape),
+          T.conv2d_transpose_bwd_filter(np.abs(f8(x)), np.abs(f8(dy)), wt.shape))

@@ -27,7 +27,7 @@ from tg import dist as tgdist
 import bench
 mode = {mode!r}
 rank = int(os.environ['RANK'])
-if mode == 'fail' and rank == 1:
+if mode == 'fail' and rank == int(os.environ['WORLD_SIZE']) - 1:
     sys.exit(3)
 world, rank, local = tgdist.init(backend='gloo')
 t = torch.full((4,), float(rank + 1))
@@ -41,12 +41,18 @@ class Store(object):
         self.p = t
 same = bench.replicas_identical(dict(a=Store(torch.arange(1000, dtype=torch.float32) * 0.37), b=Store(torch.ones(33))), 'cpu')
 differ = bench.replicas_identical(dict(a=Store(torch.arange(1000, dtype=torch.float32) * 0.37 + (1e-7 if rank else 0.0))), 'cpu')
+# the execution-mode decision of EXEC_MODE = 'auto' (Train._auto_mode -> tg.dist.decide_together): locally every rank but the last finds
+# 'plan' faster; the last rank's plan time is the slowest of all -> every replica must take 'graph', with the same timings
+local = dict(plan=14.5e-3 + (2e-3 if rank == world - 1 else 0.0), graph=15.0e-3 + 1e-5 * rank)
+pick, worst = tgdist.decide_together(local, 'cpu')
+picks = tgdist.minmax_over_ranks([float(pick == 'graph'), worst['plan'], worst['graph']], 'cpu')
 tgdist.barrier()
 if mode == 'fail':
     time.sleep(120)                       # never reached by a healthy job: the launcher stops this rank when rank 1 fails
 if rank == 0:
     print(json.dumps(dict(n_gpus=world, ranks=tgdist.rccl_ranks(), backend=tgdist.backend_name(), sum=t.tolist(), slow=slow,
-                          spawned=os.environ.get('TG_SPAWNED'), tested=tested, lo=lo, hi=hi, same=same, differ=differ)), flush=True)
+                          spawned=os.environ.get('TG_SPAWNED'), tested=tested, lo=lo, hi=hi, same=same, differ=differ, pick=pick,
+                          picks_agree=picks[0] == picks[1], worst=worst)), flush=True)
 else:
     print("rank 1 must stay silent on stdout", flush=True)
 tgdist.shutdown()
@@ -68,7 +74,36 @@ def test_spawned_ranks_report_one_line_from_rank_zero(tmp_path):
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out == dict(n_gpus=2, ranks=2, backend='gloo', sum=[3.0] * 4, slow=2.0, spawned='1',
-                       tested=2, lo=[0.0, 5.0], hi=[1.0, 5.0], same=True, differ=False)
+                       tested=2, lo=[0.0, 5.0], hi=[1.0, 5.0], same=True, differ=False, pick='graph', picks_agree=True,
+                       worst=dict(plan=16.5e-3, graph=15.0e-3 + 1e-5))
+
+
+def test_eight_spawned_ranks(tmp_path):
+    """the driver's N = 8 launch shape, rehearsed on the CPU over gloo: rendezvous, the exchange self-test, replica checksums, the
+    collective execution-mode decision (one straggler rank decides for all) — one JSON line from rank 0."""
+    r = _job(tmp_path, 'ok', n=8)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith('[Gloo]')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == dict(n_gpus=8, ranks=8, backend='gloo', sum=[36.0] * 4, slow=8.0, spawned='1',
+                       tested=8, lo=[0.0, 5.0], hi=[7.0, 5.0], same=True, differ=False, pick='graph', picks_agree=True,
+                       worst=dict(plan=16.5e-3, graph=15.0e-3 + 7e-5))
+
+
+def test_a_failing_rank_of_eight_fails_the_job(tmp_path):
+    t0 = time.time()
+    r = _job(tmp_path, 'fail', n=8)
+    assert r.returncode == 3 and '{' not in r.stdout, (r.returncode, r.stdout, r.stderr[-1000:])
+    assert time.time() - t0 < 120         # the seven healthy ranks were terminated, not waited for
+
+
+def test_communicator_id_rendezvous_of_eight(tmp_path):
+    w = tmp_path / 'idw.py'
+    w.write_text(ID_WORKER.format(pkg=PKG))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'TORCHELASTIC_USE_AGENT_STORE')}
+    r = subprocess.run([sys.executable, '-c', PARENT.format(pkg=PKG, n=8, script=str(w))], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == 'id ok', (r.stdout, r.stderr[-2000:])
 
 
 def test_a_failing_rank_fails_the_job_and_stops_the_others(tmp_path):
@@ -109,6 +144,9 @@ def test_device_count_reads_sysfs_and_the_launcher_never_opens_the_gpu(tmp_path)
     assert launch.visible_devices({'HIP_VISIBLE_DEVICES': ''}, str(nodes), none) == 0
     assert launch.visible_devices({'ROCR_VISIBLE_DEVICES': '1', 'HIP_VISIBLE_DEVICES': '0,1'}, str(nodes), none) == 1
     assert launch.visible_devices({'HIP_VISIBLE_DEVICES': '0,7,1'}, str(nodes), none) == 1      # an out-of-range index ends the list
+    assert launch.visible_devices({'HIP_VISIBLE_DEVICES': '-1'}, str(nodes), none) == 0         # the usual way to hide every device
+    assert launch.visible_devices({'HIP_VISIBLE_DEVICES': '1,-1,2'}, str(nodes), none) == 1     # a negative index ends the list
+    assert launch.visible_devices({'HIP_VISIBLE_DEVICES': '2,2,0,2'}, str(nodes), none) == 2    # a repeated index is one device
     (tmp_path / 'renderD128').write_text('')                                                    # container: one device file passed through
     assert launch.visible_devices({}, str(nodes), str(tmp_path / 'renderD*')) == 1
     assert launch.visible_devices({}, str(tmp_path / 'absent'), str(tmp_path / 'renderD*')) == 1
@@ -154,7 +192,7 @@ def test_rendezvous_names_the_rank_that_never_arrived(tmp_path):
     assert time.time() - t0 < 60
     env = dict(env, RANK='1', LOCAL_RANK='1', MASTER_PORT=str(launch.free_port()))
     r = subprocess.run([sys.executable, str(w)], env=env, capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and ('no rendezvous store' in r.stderr or 'did not publish' in r.stderr), r.stderr[-1500:]
+    assert r.returncode != 0 and ('no rendezvous store' in r.stderr or 'did not publish' in r.stderr or 'never confirmed' in r.stderr), r.stderr[-1500:]
 
 
 def test_communicator_id_rendezvous_under_an_agent_store(tmp_path):
