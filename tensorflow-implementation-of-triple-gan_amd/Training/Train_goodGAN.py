@@ -57,6 +57,7 @@ class Train(Train_base):
         self._warm_keys = set()
         self.iteration = 0
         self._exposed = None             # [(mark before, mark after)] of the waits for gradient buckets while measure_exposed(True)
+        self._label_override = {}        # see label_override()
         self.summary_train = self.summary_val = None
         if getattr(config, 'SUMMARY', False) and log_dir and self.rank == 0:          # :37-41
             from Training.Summary import Summary
@@ -126,6 +127,9 @@ class Train(Train_base):
                 c_logits, _ = m.classifier(xz, True, segments=[c.BATCH_SIZE_U_C, c.BATCH_SIZE_U_D])
             cx.join_wgrad_side()
             oh = ops.argmax_onehot(c_logits, c.NUM_CLASSES)                       # [C_unl_hard | C_unl_d_hard]
+            self._d_logits = c_logits                    # (parity tests read the logits the labels were taken from)
+            if self._label_override.get('D') is not None:      # parity tests against a precomputed fixture: see label_override()
+                oh.copy_(self._label_override['D'])
             k = c.NUM_CLASSES
             oh_unl = Act(oh[:c.BATCH_SIZE_U_C * k], c.BATCH_SIZE_U_C, 1, 1, k, k)
             oh_unl_d = Act(oh[c.BATCH_SIZE_U_C * k:], c.BATCH_SIZE_U_D, 1, 1, k, k)
@@ -171,7 +175,11 @@ class Train(Train_base):
                 c_logits, _ = m.classifier(xc, True, segments=segs)
             c_unl = c_logits.view_rows(segs[0], segs[0] + segs[1])
             k = c.NUM_CLASSES
-            oh_unl = Act(ops.argmax_onehot(c_unl, k), c_unl.n, 1, 1, k, k)
+            oh_c = ops.argmax_onehot(c_unl, k)
+            self._c_logits = c_unl
+            if self._label_override.get('C') is not None:
+                oh_c.copy_(self._label_override['C'])
+            oh_unl = Act(oh_c, c_unl.n, 1, 1, k, k)
             with cx.rng_scoped('C/D'):
                 _, d_unl = m.discriminator(self.x_u_c_ph, oh_unl, want_prob=False)
             self._c_loss(c_logits, segs[0], segs[1], segs[1] if rep else 0, G.n, self.y_l_c_ph, self.y_g_ph, d_unl,
@@ -255,6 +263,17 @@ class Train(Train_base):
         if dev:
             ops.copy_many(dev)                   # device-resident batch: all placeholders in one launch
 
+    def label_override(self, d_labels=None, c_labels=None):
+        """TEST HOOK (eager launches only).  The discriminator's labels for unlabelled images are the arg-max of the classifier's logits
+        (Model/Good_GAN.py:447-455, Good_GAN_cifar10.py:243-262): a near-tie can come out differently under another summation order or operand
+        rounding, and the discriminator's gradient then differs for a reason that is not the discriminator's.  A test that compares against a
+        PRECOMPUTED oracle run hands in the one-hot labels that run used — d_labels: [U_C + U_D, k] host array for the D-update ([C_unl | C_unl_d]),
+        c_labels: [U_C, k] for the C-update — after checking on the logits (kept in _d_logits / _c_logits) that every disagreement is a
+        near-tie.  None clears."""
+        cx = self.cx
+        to_dev = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(-1)).to(cx.device)
+        self._label_override = {'D': to_dev(d_labels), 'C': to_dev(c_labels)}
+
     def sample_latent(self):
         """z ~ U(-1,1), y ~ onehot(U{0..9}) (:234-239) drawn on the device."""
         cx = self.cx
@@ -290,6 +309,8 @@ class Train(Train_base):
                       "use TG_DIST_BACKEND=rccl-direct for graphs" % tgdist.backend_name(), flush=True)
             self._warned_eager = True
             use_graph = False
+        if (use_graph or use_plan) and any(v is not None for v in self._label_override.values()):
+            raise lib.TgError("label_override() is a test hook of eager launches: a replayed graph / launch plan would not see it")
         segs = self._segments(pre_train)
         if self._graphs is None:
             self._graphs = {}

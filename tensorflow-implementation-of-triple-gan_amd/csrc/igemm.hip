@@ -55,6 +55,17 @@ __device__ __forceinline__ u32x2 pack4_bf16(u32x4 v) {          // 4 fp32 -> 4 b
   return __builtin_bit_cast(u32x2, __builtin_convertvector(__builtin_bit_cast(f32x4, v), bf16x4_t));
 }
 
+// register stages of igemm_f32_kernel's K pipeline per tile class (128x128 / 128x64 and 64x128 / smaller); -D overrides are for A/B builds
+#ifndef TG_PF_BIG
+#define TG_PF_BIG 1
+#endif
+#ifndef TG_PF_MID
+#define TG_PF_MID 2
+#endif
+#ifndef TG_PF_SMALL
+#define TG_PF_SMALL 3
+#endif
+
 constexpr int BK = 32;    // reduction depth per LDS tile
 constexpr int LDT = 36;   // padded LDS row stride (floats)
 constexpr int LDH = 80;   // bf16 variant: LDS row stride in BYTES (32 bf16 = 64 B + 16 B pad: the 16 rows of a ds_read_b128 lane group hit 16 different 16-B bank slots)
@@ -145,6 +156,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
   constexpr int AR = BM / 32, BR = BN / 32;   // 16-B loads per thread per tile
+  constexpr int PF = FIXUP ? 1 : (BM * BN >= 128 * 128 ? TG_PF_BIG : (BM * BN >= 128 * 64 ? TG_PF_MID : TG_PF_SMALL));      // register stages of the K pipeline (see the K loop)
   __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDT + 2 * BN * LDT + 4 * BM];
   float* As = smem;
   float* Bs = smem + 2 * BM * LDT;
@@ -238,7 +250,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
 #pragma unroll
   for (int j = 0; j < BR; ++j) wvoff[j] = (uint32_t)(((int64_t)(n0 + lrow + 32 * j) * p.w_sn + seg * 4) * 4);
 
-  u32x4 ra[AR], rb[BR];
+  u32x4 ra[PF][AR], rb[PF][BR];
   uint32_t avoff[AR];
   const int cchunks = p.ld_in / BK;
   const int nk = d.n_taps * cchunks;
@@ -256,15 +268,15 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       avoff[j] = ok ? (uint32_t)(abase[j] + (iy * w_in + ix) * ld_in) * 4u : OOB_OFF;
     }
   };
-  auto gload = [&](int c0) {
+  auto gload = [&](int c0, int rs) {                     // rs: register stage (a compile-time constant after unrolling)
     const uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane(c0 * 4);
     const uint32_t sw = (uint32_t)__builtin_amdgcn_readfirstlane((w_tap_off + c0) * 4);
 #pragma unroll
-    for (int j = 0; j < AR; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, avoff[j], sa, 0);
+    for (int j = 0; j < AR; ++j) ra[rs][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, avoff[j], sa, 0);
 #pragma unroll
-    for (int j = 0; j < BR; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wvoff[j], sw, 0);
+    for (int j = 0; j < BR; ++j) rb[rs][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wvoff[j], sw, 0);
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, int rs) {
     if constexpr (BF16) {
       // bf16 LDS images (round 3): the operands are rounded ONCE on the global -> LDS path (v_cvt_pk_bf16_f32, RNE) and a 32-deep row is
       // 64 bytes — half the LDS bytes of the fp32 image, and the fragments below need no conversion (round 2 converted every fragment
@@ -272,16 +284,16 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       unsigned char* a = reinterpret_cast<unsigned char*>(As) + (buf * BM + lrow) * LDH + seg * 8;
       unsigned char* b = reinterpret_cast<unsigned char*>(Bs) + (buf * BN + lrow) * LDH + seg * 8;
 #pragma unroll
-      for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x2*>(a + 32 * j * LDH) = pack4_bf16(ra[j]);
+      for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x2*>(a + 32 * j * LDH) = pack4_bf16(ra[rs][j]);
 #pragma unroll
-      for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x2*>(b + 32 * j * LDH) = pack4_bf16(rb[j]);
+      for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x2*>(b + 32 * j * LDH) = pack4_bf16(rb[rs][j]);
     } else {
       float* a = As + buf * BM * LDT + lrow * LDT + seg * 4;
       float* b = Bs + buf * BN * LDT + lrow * LDT + seg * 4;
 #pragma unroll
-      for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4*>(a + 32 * j * LDT) = ra[j];
+      for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4*>(a + 32 * j * LDT) = ra[rs][j];
 #pragma unroll
-      for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x4*>(b + 32 * j * LDT) = rb[j];
+      for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x4*>(b + 32 * j * LDT) = rb[rs][j];
     }
   };
 
@@ -314,75 +326,107 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   // K range of this unit: K-tiles [it0, it1) of the tile's nk (balanced integer cut)
   const int it0 = (int)((int64_t)nk * kseg / kcut), it1 = (int)((int64_t)nk * (kseg + 1) / kcut);
 
-  // Register-staged double buffer: the global loads of tile it+1 are issued before the 64 MFMAs of tile it and written
-  // to the other LDS buffer after them (one barrier per K-tile).  (Measured alternative: writing tile it+1 FIRST and
-  // prefetching tile it+2 — one tile deeper — is 3-4 % slower here and 5 % faster in wgrad_f32_kernel, which uses it.)
-  int tap = it0 / cchunks, c0 = (it0 - tap * cchunks) * BK, buf = 0;
+  // Register-staged pipeline over a two-buffer LDS image, PF register stages deep: while tile `it` is multiplied, the loads of tiles
+  // it+1 .. it+PF are in flight (tile it+PF is issued at the top of iteration it into the stage that tile it occupied), and tile it+1 is
+  // written to the other LDS buffer after the MFMAs (one barrier per K-tile).  PF = 1 is the round-1 scheme: enough for the 128x128 tile
+  // (64 MFMAs = 1.7 us per K-tile cover a global-load latency) with two workgroups per CU; a 64x64 / 128x32 tile has 16 MFMAs = 0.43 us
+  // per K-tile, and the launches that use them are the under-filled ones (one workgroup on most CUs), so one tile of lookahead leaves the
+  // load latency exposed in EVERY K-tile — three stages cover ~1.3 us.
+  int tap = it0 / cchunks, c0 = (it0 - tap * cchunks) * BK, buf = 0, issued = it0;
   set_tap(tap);
-  gload(c0);
-  sstore(0);
+  auto issue = [&](int rs) {                             // loads of tile `issued` into register stage rs; advances the (tap, channel chunk) cursor
+    gload(c0, rs);
+    ++issued;
+    c0 += BK;
+    if (c0 == ld_in) { c0 = 0; ++tap; if (issued < it1) set_tap(tap); }
+  };
+#pragma unroll
+  for (int rs = 0; rs < PF; ++rs)
+    if (it0 + rs < it1) issue(rs);
+  sstore(0, 0);
   __syncthreads();
 
 #ifdef TG_STAMP
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, acc_load = 0, acc_mfma = 0, acc_store = 0, acc_bar = 0, t_begin = 0;
   STAMP(t_begin);
 #endif
-  for (int it = it0; it < it1; ++it) {
-    const bool more = it + 1 < it1;
-    STAMP(ts0);
-    if (more) {
-      c0 += BK;
-      if (c0 == ld_in) { c0 = 0; set_tap(++tap); }
-      gload(c0);
-    }
-    STAMP(ts1);
-    const float* A = As + buf * BM * LDT + wm0 * LDT + frag;
-    const float* B = Bs + buf * BN * LDT + wn0 * LDT + frag;
+  // one K-tile: the MFMAs of the tile in LDS buffer `b`
+  auto compute = [&](int b) {
     if constexpr (BF16) {
       // lane (row r = lane & 31, half h = lane >> 5) supplies k = 16 G + 8 h + (0..7) of 16-deep group G for BOTH operands: one 16-byte read
-      const unsigned char* Ab = reinterpret_cast<const unsigned char*>(As) + (buf * BM + wm0 + (lane & 31)) * LDH + (lane >> 5) * 16;
-      const unsigned char* Bb = reinterpret_cast<const unsigned char*>(Bs) + (buf * BN + wn0 + (lane & 31)) * LDH + (lane >> 5) * 16;
+      const unsigned char* Ab = reinterpret_cast<const unsigned char*>(As) + (b * BM + wm0 + (lane & 31)) * LDH + (lane >> 5) * 16;
+      const unsigned char* Bb = reinterpret_cast<const unsigned char*>(Bs) + (b * BN + wn0 + (lane & 31)) * LDH + (lane >> 5) * 16;
 #pragma unroll
       for (int G = 0; G < BK / 16; ++G) {
-        bf16x8 a[MI], b[NI];
+        bf16x8 fa[MI], fb[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * LDH + G * 32);
+        for (int mi = 0; mi < MI; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * LDH + G * 32);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * LDH + G * 32);
+        for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * LDH + G * 32);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            if (COLSUM) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+            if (COLSUM) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
       }
     } else {
+      const float* A = As + b * BM * LDT + wm0 * LDT + frag;
+      const float* B = Bs + b * BN * LDT + wn0 * LDT + frag;
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      f32x4 a[MI], b[NI];
+      for (int g = 0; g < BK / 8; ++g) {
+        f32x4 fa[MI], fb[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(A + mi * 32 * LDT + g * 8);
+        for (int mi = 0; mi < MI; ++mi) fa[mi] = *reinterpret_cast<const f32x4*>(A + mi * 32 * LDT + g * 8);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(B + ni * 32 * LDT + g * 8);
+        for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const f32x4*>(B + ni * 32 * LDT + g * 8);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+          for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            if (COLSUM) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);   // D[m][n]: lane = channel
-            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][s], a[mi][s], acc[mi][ni], 0, 0, 0);        // D[n][m]: lane = pixel
+            for (int ni = 0; ni < NI; ++ni)
+              if (COLSUM) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][s], fb[ni][s], acc[mi][ni], 0, 0, 0);   // D[m][n]: lane = channel
+              else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni][s], fa[mi][s], acc[mi][ni], 0, 0, 0);        // D[n][m]: lane = pixel
+      }
     }
-    }
-    STAMP(ts2);
-    if (more) sstore(buf ^ 1);
-    STAMP(ts3);
-    __syncthreads();
-    STAMP(ts4);
+  };
+  int it = it0;
+  // steady state, PF iterations at a time, each issuing one tile UNCONDITIONALLY: straight-line code, so the wait in front of the LDS
+  // write of stage rs + 1 is a counted one (the PF - 1 younger tiles stay in flight) — with a branch around the issue the compiler has to
+  // assume the youngest loads are the ones it needs and drains the queue every iteration
+  while (issued + PF <= it1) {
+#pragma unroll
+    for (int rs = 0; rs < PF; ++rs) {
+      STAMP(ts0);
+      issue(rs);                                         // stage rs went to LDS in the previous iteration (or in the prologue)
+      STAMP(ts1);
+      compute(buf);
+      STAMP(ts2);
+      sstore(buf ^ 1, (rs + 1) % PF);
+      STAMP(ts3);
+      __syncthreads();
+      STAMP(ts4);
 #ifdef TG_STAMP
-    acc_load += ts1 - ts0; acc_mfma += ts2 - ts1; acc_store += ts3 - ts2; acc_bar += ts4 - ts3;
+      acc_load += ts1 - ts0; acc_mfma += ts2 - ts1; acc_store += ts3 - ts2; acc_bar += ts4 - ts3;
 #endif
-    buf ^= 1;
+      buf ^= 1;
+    }
+    it += PF;
+  }
+  // drain (and K ranges shorter than the pipeline): fewer than 2 PF iterations; the stage loop must unroll completely — its index names
+  // registers — hence guards, not breaks
+  for (; it < it1; it += PF) {
+#pragma unroll
+    for (int rs = 0; rs < PF; ++rs) {
+      if (it + rs < it1) {
+        if (issued < it1) issue(rs);
+        compute(buf);
+        if (it + rs + 1 < it1) sstore(buf ^ 1, (rs + 1) % PF);
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
   }
 #ifdef TG_STAMP
   {

@@ -51,6 +51,39 @@ def test_goodgan_oracle_reproduces_the_golden_prefix():
         assert g['sample_final'].shape[0] == M.N_SAMPLE and np.isfinite(g['losses']).all()
 
 
+def test_svhn_bf16_reference_size_fixture_is_what_the_oracle_computes():
+    """tests/golden/goodgan_svhn_bf16_step_ref.npz (make_golden_svhn_bf16_step.py: configs[3] at 100 / 50 / 50 / 20 / 80, float64 oracle with its
+    bf16 emulation, D- / G- / C-update each from the initial weights): the cheapest of the three solver runs — the G-update, 3 s — is recomputed
+    and digested here; the file holds every variable of every run and its own invariants."""
+    import copy
+    import make_golden_svhn_bf16_step as M
+    from oracle import step_goodgan as S
+    from oracle import tf_ops as T
+    fx = M.load()
+    P0 = M.init_params()
+    b, rnd = M.inputs()
+    T.MFMA_BF16 = True
+    try:
+        st = S.new_state(M.f64(P0))
+        loss = S.g_phase(st, M.DATA, M.f64(b), M.f64(rnd)['G'], M.HYPER)
+    finally:
+        T.MFMA_BF16 = False
+    np.testing.assert_allclose(loss, float(fx['loss/G']), rtol=1e-9)
+    for k, g in st['last_grads']['G'].items():
+        d = M.summary(k, g)
+        np.testing.assert_allclose(d['l2'], float(fx['grad/G/%s/l2' % k]), rtol=1e-9)
+        np.testing.assert_allclose(d['proj'], fx['grad/G/%s/proj' % k], rtol=1e-7, atol=1e-9 * d['l2'])
+        np.testing.assert_allclose(d['sample'], fx['grad/G/%s/sample' % k], rtol=1e-6, atol=1e-7 * d['amax'])      # stored as float32
+    for phase, n_vars in (('D', 0), ('G', 0), ('C', 0)):
+        names = [k for k in fx if k.startswith('grad/%s/' % phase) and k.endswith('/l2')]
+        assert len(names) >= 10 and all(np.isfinite(fx[k]) and float(fx[k]) > 0 for k in names), phase
+    assert fx['d_labels_logits/unl'].shape == (M.SIZES['U_C'], 10) and fx['d_labels_logits/unl_d'].shape == (M.SIZES['U_D'], 10)
+    assert fx['c_labels_logits/unl'].shape == (M.SIZES['U_C'], 10)
+    # with bf16 operands the run is NOT the exact-fp32 one: the same G-update without the emulation differs visibly in its loss
+    st2 = S.new_state(M.f64(P0))
+    assert abs(S.g_phase(st2, M.DATA, M.f64(b), M.f64(rnd)['G'], M.HYPER) - loss) > 1e-6
+
+
 def test_oracle_reproduces_the_long_horizon_prefix():
     """tests/golden/cifar10_long_<fixture>_<variant>.npz (make_golden_long.py: 300 free-running iterations, error rate on 1 000 images at
     the fixture's checkpoints, float64 + float32 controls) — the first iteration of every fixture is recomputed here (float64 to 1e-9; the

@@ -15,15 +15,28 @@ tests/debug/debug_long_horizon_lag.py (profiles/r03_long_horizon_lag.txt) shows 
 gradient error in every variable of every one of the first 40 iterations when started from identical weights, and the float32 controls
 now show the same spread without any HIP kernel involved.
 
+Round 4: an ENSEMBLE of HIP trajectories against the ensemble of control runs.  One HIP draw against a band three control-ranges wide
+(round 3) cannot tell chance from a small systematic term; the path has several equally accurate float32 summation orders of its own —
+the 3x3 layers on the halo-tiled kernels (default routing) or wherever they apply (tg_conv3x3_policy 1), the filter-gradient pixel
+split as the library sets it or halved — and both launch paths (one stream / second-stream overlap; bit-identical arithmetic, so that
+the overlap path is held to the acceptance number too).  MEMBERS below = 4 trajectories per fixture.
+
 Checks, all derived from the committed control runs (no hand-set window, no exemption):
-  1. every checkpoint: the HIP error lies in the controls' range at that checkpoint and its two neighbours, extended on either side by
-     the width of that range (for n exchangeable runs the chance of a further one falling outside shrinks fast with n; where the controls
-     agree — the plateau — the extension is 0) and by the north star's 0.3 pp;
-  2. the SETTLING ITERATION (first checkpoint from which on the error stays within 0.3 pp of float64's final error) lies in the controls'
-     range of settling iterations extended by its own width: a lead or lag is bounded in iterations;
-  3. the final checkpoint and the mean over the last third of the run are within 0.3 pp of the controls' range (extended by its width: no
-     implementation can be closer to "the" reference than the reference's float32 evaluations are to each other; the width is 0 on
-     'k300') — the acceptance number.
+  1. every member, every checkpoint FROM THE ITERATION ON BY WHICH CHECK 2 REQUIRES A RUN TO HAVE SETTLED: inside the controls' range at that
+     checkpoint and its two neighbours, extended on either side by the width of that range + 0.3 pp — on the plateau the controls agree and
+     this is the north star's 0.3 pp.  Before that iteration nothing per-checkpoint is asserted: the controls themselves are 5.7 % ... 65 %
+     apart at iteration 50 of 'k300' (the run is chaotic while the error falls; round 3's per-checkpoint envelope there was [-54 %, 124 %],
+     i.e. vacuous, and a 5 pp clamp on it rejects late-settling HIP members the way it would reject late-settling controls) — the
+     descent is judged by check 2, the full tables go to gpurun_out/long_horizon_<fixture>.json.
+  2. every member: the SETTLING ITERATION (first checkpoint from which on the error stays within 0.3 pp of float64's final error) within
+     F_ONE * s * sqrt(1 + 1/n_c) + (the checkpoint spacing there: the resolution of the measurement) of the controls' mean settling
+     iteration, s = their sample standard deviation: a lead or lag is bounded in iterations.
+  3. THE ACCEPTANCE NUMBER, on the final checkpoint and on the mean over the last third of the run:
+       | mean over the HIP members - mean over the control runs |  <=  F_ENS * s_c * sqrt(1/n_c + 1/n_h) + 0.3 pp
+     s_c = the controls' sample standard deviation (n_c = 4 - 5 runs incl. float64), n_h = 4, F_ENS = 2.5 (two-sided ~98 % for a
+     difference of means of exchangeable runs) — the standard error of the comparison, not the range tripled; where the reference
+     reproduces itself (s_c = 0: the 'k300' plateau) this IS +-0.3 pp.  And no single member further from the controls' mean than
+     F_ONE * s_c * sqrt(1 + 1/n_c) + 0.3 pp (F_ONE = 3: a prediction interval for one more exchangeable run).
 Fixture 'hard' (class blends: a genuinely ambiguous task whose error does NOT fall to zero, last 100 iterations at 2.5x the batch sizes)
 makes 3. a statement about a classifier that is still imperfect; on 'k300' the plateau is 0.0 %.  Fixture 'ref' is the 'hard' task with
 the last 50 iterations at the REFERENCE's batch sizes (100 / 50 / 50 / 20 / 80: the bench configuration's launch shapes, halo-tiled kernels
@@ -42,6 +55,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'golden'))
 pytestmark = pytest.mark.gpu
 PP = 0.003 + 1e-9                 # +-0.3 percentage points
+F_ENS, F_ONE = 2.5, 3.0           # factors on the controls' standard error (ensemble mean) / standard deviation (one member): module docstring
+# the HIP path's own equally accurate evaluations of a trajectory: 3x3 routing x filter-gradient pixel split, on both launch paths
+MEMBERS = [dict(name='default routing, library split, overlap', policy=None, split_div=1, mode='overlap'),
+           dict(name='halo kernels everywhere, library split, one stream', policy=1, split_div=1, mode='eager'),
+           dict(name='default routing, half split, one stream', policy=None, split_div=2, mode='eager'),
+           dict(name='halo kernels everywhere, half split, overlap', policy=1, split_div=2, mode='overlap')]
 
 
 def _state_of(tr):
@@ -57,12 +76,17 @@ def _load_state(tr, state):
             s.ema.copy_(state[n]['ema'])
 
 
-def run_hip(M, fixture, policy=None):
-    """the fixture's run on the HIP path -> ({checkpoint: error rate}, per-iteration losses)."""
+def run_hip(M, fixture, policy=None, split_div=1, mode='auto'):
+    """the fixture's run on the HIP path -> ({checkpoint: error rate}, per-iteration losses).  policy: tg_conv3x3_policy for the run;
+    split_div: the filter gradients' pixel split (tg_wgrad_splits) divided by this — another partition of the same sums; mode:
+    config.EXEC_MODE ('eager' = one stream, 'overlap' / 'auto' = filter gradients on the second stream)."""
     import torch
     from oracle import step_cifar10 as S
-    from tg import lib
+    from tg import geom, lib
     from tg.runtime import InjectedRNG
+    lib_splits = geom.wgrad_splits
+    if split_div > 1:
+        geom.wgrad_splits = lambda d, bf16=False: max(1, lib_splits(d, bf16) // split_div)
     xt, yt, noise = M.test_split(fixture)
     steps = [e for e in M.FIXTURES[fixture]['evals']]
     total = M.total_steps(fixture)
@@ -74,7 +98,7 @@ def run_hip(M, fixture, policy=None):
         for n_it, sizes in M.FIXTURES[fixture]['phases']:
             if tr is not None:
                 state = _state_of(tr)
-            tr = G.fresh_trainer(G.make_config(sizes), S.init_params(0) if state is None else None)
+            tr = G.fresh_trainer(G.make_config(sizes, EXEC_MODE=mode), S.init_params(0) if state is None else None)
             if state is not None:
                 _load_state(tr, state)               # the next phase's batch sizes: a new trainer (static placeholders) on the same state
             tr.set_hyper(M.HYPER['lr'], M.HYPER['cla_lr'], M.HYPER['lambda_1'], M.HYPER['lambda_2'])
@@ -97,6 +121,7 @@ def run_hip(M, fixture, policy=None):
                     err[k] = error_rate()
         torch.cuda.synchronize()
     finally:
+        geom.wgrad_splits = lib_splits
         if was is not None:
             lib.call('tg_conv3x3_policy', was)
     return err, np.asarray(losses)
@@ -118,7 +143,7 @@ def _fixtures():
 
 
 @pytest.mark.parametrize("fixture", _fixtures())
-def test_error_rate_stays_inside_the_envelope_of_the_cpu_reference_runs(fixture):
+def test_error_rate_ensemble_against_the_cpu_reference_runs(fixture):
     import make_golden_long as M
     ctl = M.load(fixture)
     assert len(ctl) >= 3, "a float64 run and at least two float32 controls"
@@ -126,39 +151,59 @@ def test_error_rate_stays_inside_the_envelope_of_the_cpu_reference_runs(fixture)
     for v in ctl.values():
         assert [int(s) for s in v['eval_steps']] == steps
     cerr = {name: 1.0 - v['eval_acc'] for name, v in ctl.items()}            # variant -> errors at the checkpoints
-    got, losses = run_hip(M, fixture)
-    herr = [got[s] for s in steps]
-    table = [dict(step=s, hip_error=float(h), **{name: float(e[i]) for name, e in cerr.items()}) for i, (s, h) in enumerate(zip(steps, herr))]
+    all_err = np.stack(list(cerr.values()))                                   # [variant, checkpoint]
+    n_c = all_err.shape[0]
+    runs = []
+    for mb in MEMBERS:
+        got, losses = run_hip(M, fixture, mb['policy'], mb['split_div'], mb['mode'])
+        runs.append(dict(name=mb['name'], err=[float(got[s]) for s in steps], losses=losses))
+    herr = np.asarray([r['err'] for r in runs])                               # [member, checkpoint]
+    n_h = herr.shape[0]
+    table = [dict(step=s, hip=[float(v) for v in herr[:, i]], **{name: float(e[i]) for name, e in cerr.items()}) for i, s in enumerate(steps)]
+    tail = [i for i, s in enumerate(steps) if s > steps[-1] * 2 // 3]
+    stats = {}
+    for name, idx in (('final', [len(steps) - 1]), ('mean over the last third', tail)):
+        c = all_err[:, idx].mean(axis=1)
+        h = herr[:, idx].mean(axis=1)
+        s_c = float(c.std(ddof=1))
+        stats[name] = dict(controls=[float(v) for v in c], hip=[float(v) for v in h], controls_mean=float(c.mean()), hip_mean=float(h.mean()),
+                           s_c=s_c, bound_ensemble=F_ENS * s_c * float(np.sqrt(1.0 / n_c + 1.0 / n_h)) + PP,
+                           bound_member=F_ONE * s_c * float(np.sqrt(1.0 + 1.0 / n_c)) + PP)
     dbg = os.path.join(os.path.dirname(HERE), 'gpurun_out')
     if os.path.isdir(dbg):
-        json.dump(dict(fixture=fixture, table=table, hip_losses=losses.tolist()), open(os.path.join(dbg, 'long_horizon_%s.json' % fixture), 'w'), indent=1)
-    # identical weights, deterministic evaluation: the initial error is the same number (an arg-max tie at most)
-    assert abs(herr[0] - cerr['f64'][0]) <= 1.0 / M.N_TEST + 1e-9, table[0]
-    # 1. per checkpoint, against the controls' range in a window of one checkpoint either side
-    all_err = np.stack(list(cerr.values()))                                   # [variant, checkpoint]
-    for i, s in enumerate(steps):
-        win = all_err[:, max(0, i - 1):i + 2]
-        lo, hi = float(win.min()), float(win.max())
-        w = hi - lo
-        assert lo - w - PP <= herr[i] <= hi + w + PP, ('checkpoint', s, herr[i], (lo, hi), table)
-    # 2. the settling iteration
+        json.dump(dict(fixture=fixture, members=[r['name'] for r in runs], table=table, acceptance=stats,
+                       hip_losses=[r['losses'].tolist() for r in runs]), open(os.path.join(dbg, 'long_horizon_%s.json' % fixture), 'w'), indent=1)
     level = float(cerr['f64'][-1]) + PP
     c_settle = [settling_step(steps, list(e), level) for e in cerr.values()]
-    h_settle = settling_step(steps, herr, level)
-    ws = max(c_settle) - min(c_settle)
-    assert min(c_settle) - ws <= h_settle <= max(c_settle) + ws, ('settling iteration', h_settle, sorted(c_settle), table)
-    # 3. the acceptance number: the end of the run and the mean over its last third
-    tail = [i for i, s in enumerate(steps) if s > steps[-1] * 2 // 3]
-    for name, idx in (('final', [len(steps) - 1]), ('mean over the last third', tail)):
-        c = [float(np.mean(e[idx])) for e in cerr.values()]
-        h = float(np.mean([herr[i] for i in idx]))
-        w = max(c) - min(c)                          # 0 where the reference reproduces itself ('k300'): then this IS +-0.3 pp
-        assert min(c) - w - PP <= h <= max(c) + w + PP, (name, h, (min(c), max(c)), table)
-    # the losses stay on the controls' scale (GAN losses fluctuate: bound = the controls' spread around float64 over the neighbouring
-    # 25 iterations, per loss)
+    # a settling iteration is only known to the checkpoint spacing around it (k300: every 5 iterations up to 100, every 25 from there on)
+    res = max(b - a for a, b in zip(steps, steps[1:]) if a <= max(c_settle) + 1 and b >= min(c_settle))
+    settle_tol = F_ONE * float(np.std(c_settle, ddof=1)) * float(np.sqrt(1.0 + 1.0 / n_c)) + res
     ref = ctl['f64']['losses']
     dev = np.max([np.abs(v['losses'] - ref) for n, v in ctl.items() if n != 'f64'], axis=0)      # [iteration, 3]
-    for k in range(24, len(losses), 25):
-        lo, hi = max(0, k - 25), min(len(losses), k + 25)
-        allowed = 2.0 * dev[lo:hi].max(axis=0) + ref[lo:hi].std(axis=0) + 0.05
-        assert np.all(np.abs(losses[k] - ref[k]) <= allowed), (k + 1, losses[k], ref[k], allowed)
+    for r, he in zip(runs, herr):
+        # identical weights, deterministic evaluation: the initial error is the same number (an arg-max tie at most)
+        assert abs(he[0] - cerr['f64'][0]) <= 1.0 / M.N_TEST + 1e-9, (r['name'], table[0])
+        # 1. per checkpoint, against the controls' range in a window of one checkpoint either side — from the iteration on by which check 2
+        # requires every run to have settled (before it the trajectory is chaotic: what is asserted there is check 2's bound on the lag)
+        for i, s in enumerate(steps):
+            if s < np.mean(c_settle) + settle_tol:
+                continue
+            win = all_err[:, max(0, i - 1):i + 2]
+            lo, hi = float(win.min()), float(win.max())
+            w = hi - lo
+            assert lo - w - PP <= he[i] <= hi + w + PP, (r['name'], 'checkpoint', s, he[i], (lo, hi), table)
+        # 2. the settling iteration
+        h_settle = settling_step(steps, list(he), level)
+        assert abs(h_settle - np.mean(c_settle)) <= settle_tol, (r['name'], 'settling iteration', h_settle, sorted(c_settle), settle_tol, table)
+        # the losses stay on the controls' scale (GAN losses fluctuate: bound = the controls' spread around float64 over the neighbouring
+        # 25 iterations, per loss)
+        losses = r['losses']
+        for k in range(24, len(losses), 25):
+            lo, hi = max(0, k - 25), min(len(losses), k + 25)
+            allowed = 2.0 * dev[lo:hi].max(axis=0) + ref[lo:hi].std(axis=0) + 0.05
+            assert np.all(np.abs(losses[k] - ref[k]) <= allowed), (r['name'], k + 1, losses[k], ref[k], allowed)
+    # 3. the acceptance number: ensemble mean against ensemble mean, and every member against the controls' mean
+    for name, st in stats.items():
+        assert abs(st['hip_mean'] - st['controls_mean']) <= st['bound_ensemble'], (name, 'ensemble', st)
+        for r, h in zip(runs, st['hip']):
+            assert abs(h - st['controls_mean']) <= st['bound_member'], (name, r['name'], h, st)
