@@ -63,7 +63,7 @@ __device__ __forceinline__ u32x2 pack4_bf16(u32x4 v) {          // 4 fp32 -> 4 b
 #define TG_PF_MID 2
 #endif
 #ifndef TG_PF_SMALL
-#define TG_PF_SMALL 3
+#define TG_PF_SMALL 2
 #endif
 
 constexpr int BK = 32;    // reduction depth per LDS tile

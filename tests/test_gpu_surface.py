@@ -364,3 +364,50 @@ def test_salimans_layers_and_data_dependent_init(plain):
     assert G.rel_err(yi.numpy(), 0.7 / np.sqrt(xi.var((0, 1, 2)) + 1e-8) * (xi - xi.mean((0, 1, 2)))) < 1e-4
     xd = x2d @ T.wn_weight(P('sal/dense_0/V'), ones)
     assert G.rel_err(ydi.numpy(), 1.0 / np.sqrt(xd.var(0) + 1e-10) * (xd - xd.mean(0))) < 1e-4
+
+
+def test_fused_backward_paths_refuse_a_second_consumer(plain):
+    """advisor (round 3): the batch-norm backward fusions assume ONE consumer per tensor.  (a) conv -> relu -> x, consumed by a batch norm AND by
+    a second convolution: the batch norm's backward folds relu'(x) and the bias gradient into x's gradient buffer (Act.grad_is_dpre), the other
+    consumer writes a raw gradient into the same buffer — the producing convolution must refuse to train on that buffer (Act.contribs, counted
+    in Context.grad_of) instead of treating it as its pre-activation gradient.  (b) a batch norm's OUTPUT consumed by two convolutions: the
+    backward statistics the first consumer's input-gradient launch took (Act.bn_bwd_sums) are not the statistics of the final gradient — the
+    batch norm must fall back to its own statistics pass, and then gives the oracle's gradient for the gradient buffer as it stands."""
+    from tg import lib, ops
+    cx = plain.cx
+    rng = np.random.default_rng(21)
+    n, h, c = 4, 8, 32
+    xin = rng.standard_normal((n, h, h, c)).astype(np.float32)
+    mk = lambda *s: cx.from_numpy((0.1 * rng.standard_normal(s)).astype(np.float32).reshape(1, -1)).t
+    zeros = lambda *s: cx.from_numpy(np.zeros(s, np.float32).reshape(1, -1)).t
+    wa, ba, wb, wc = mk(3, 3, c, c), mk(c), mk(3, 3, c, c), mk(3, 3, c, c)
+    gwa, gba, gwb, gwc = zeros(3, 3, c, c), zeros(c), zeros(3, 3, c, c), zeros(3, 3, c, c)
+    gamma, beta, mm, mv = cx.from_numpy(np.ones((1, c), np.float32)).t, zeros(c), zeros(c), cx.from_numpy(np.ones((1, c), np.float32)).t
+    ggam, gbet = zeros(c), zeros(c)
+
+    def graph(second_consumer_of):
+        a = cx.from_numpy(xin)
+        a.requires_grad = True
+        x = ops.conv2d(a, wa, ba, c, 3, 1, 'SAME', act='relu', kernel_grad=gwa, bias_grad=gba)
+        y = ops.batch_norm_train(x, gamma, beta, mm, mv, 1e-3, 0.9, gamma_grad=ggam, beta_grad=gbet)
+        u = ops.conv2d(y, wb, None, c, 3, 1, 'SAME', kernel_grad=gwb)
+        v = ops.conv2d(x if second_consumer_of == 'x' else y, wc, None, c, 3, 1, 'SAME', kernel_grad=gwc)
+        du = rng.standard_normal((n, h, h, c)).astype(np.float32)
+        u.grad, v.grad = cx.from_numpy(du), cx.from_numpy(du)
+        return x, y
+
+    with cx.phase_scope('twocons_a', train_nets=('discriminator',)):      # any store name: only cx.trains() matters
+        with cx.variable_scope('discriminator'):
+            graph('x')
+            with pytest.raises(lib.TgError, match='written by 2 consumers'):
+                cx.backward()
+    with cx.phase_scope('twocons_b', train_nets=('discriminator',)):
+        with cx.variable_scope('discriminator'):
+            x, y = graph('y')
+            cx.backward()
+            assert y.grad.contribs == 2 and y.bn_bwd_sums is None          # the second consumer withdrew the first one's statistics
+            gy = y.grad.numpy().astype(np.float64)
+            xr = x.numpy().astype(np.float64)
+            _, cache = T.batch_norm_train(xr, np.ones(c), np.zeros(c), 1e-3)
+            dxr, dgr, dbr = T.batch_norm_train_bwd(gy, np.ones(c), cache)
+            assert G.rel_err(ggam.cpu().numpy(), dgr) < 1e-4 and G.rel_err(gbet.cpu().numpy(), dbr) < 1e-4

@@ -117,6 +117,14 @@ def main():
     t_issue = (time.perf_counter() - t0) / args.steps     # host time to ISSUE an iteration (the queue is drained only below): when this is
     torch.cuda.synchronize()                              # close to the step time, the step is bound by the host's launch rate
     dt = (time.perf_counter() - t0) / args.steps
+    issue = []                                            # the launch path's own cost: ONE iteration issued into an empty queue (t_issue above includes
+    for _ in range(5):                                    # the time the host is blocked on a full queue once it runs ahead of the GPU)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        issue.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    t_issue_free = float(np.median(issue))
     losses = tr.losses()
     assert all(np.isfinite(losses)), losses
 
@@ -143,15 +151,26 @@ def main():
         if b.value > 0:
             e.update(gbytes=round(b.value / 1e9, 2), gb_per_s=round(b.value / ms.value / 1e6, 0), frac_of_hbm_peak=round(b.value / ms.value / 1e6 / PEAK_GBS, 3))
         classes[name] = e
-    dump = os.environ.get('TG_PROF_DUMP')
-    if dump:
-        lib.call('tg_prof_dump', dump.encode())
+    dump = os.environ.get('TG_PROF_DUMP') or os.path.join('/tmp', 'tg_prof_cfg_%d.csv' % os.getpid())
+    lib.call('tg_prof_dump', dump.encode())
+    # the three longest MFMA launches of the iteration against BOTH roofs: executed FLOP / the operand type's dense MFMA peak, and algorithmic
+    # bytes (operands once + output once, fp32 tensors in HBM) / 8 TB/s — with bf16 operands the 3x3 layers are bound by the second
+    import csv
+    peak = PEAK_TF_BF16 if cfg.MFMA_DTYPE == 'bf16' else PEAK_TF
+    rows = [r for r in csv.DictReader(open(dump)) if r['class'] in ('igemm_f32', 'wgrad_f32') and float(r['ms']) > 0]
+    rows.sort(key=lambda r: -float(r['ms']))
+    largest = [dict(kind=r['class'], shape=r['desc'], ms=round(float(r['ms']), 4), tflops=round(float(r['gflop']) / float(r['ms']), 1),
+                    frac_of_mfma_peak=round(float(r['gflop']) / float(r['ms']) / peak, 4), gb_per_s=round(float(r['gbytes']) / float(r['ms']) * 1e3, 0),
+                    frac_of_hbm_peak=round(float(r['gbytes']) / float(r['ms']) * 1e3 / PEAK_GBS, 3)) for r in rows[:3]]
+    if not os.environ.get('TG_PROF_DUMP'):
+        os.remove(dump)
     mem = torch.cuda.max_memory_allocated() / 2 ** 30
     print(json.dumps({"workload": "%s: synthetic %dx%dx%d, B_G/L_C/U_C/L_D/U_D=%d/%d/%d/%d/%d, %s D+G+C step, MFMA operands %s" % (
                           args.config, cfg.IMAGE_HEIGHT, cfg.IMAGE_WIDTH, cfg.CHANNEL, cfg.BATCH_SIZE_G, cfg.BATCH_SIZE_L_C, cfg.BATCH_SIZE_U_C,
                           cfg.BATCH_SIZE_L_D, cfg.BATCH_SIZE_U_D, Model.__name__, cfg.MFMA_DTYPE),
                       "ms_per_step": round(dt * 1e3, 3), "images_per_sec": round(cfg.BATCH_SIZE_G / dt, 1), "steps": args.steps, "hbm_gib_allocated": round(mem, 2),
-                      "host_issue_ms_per_step": round(t_issue * 1e3, 3), "exec_mode": cfg.EXEC_MODE, "exec_mode_chosen": tr.exec_mode_chosen()[0] if cfg.EXEC_MODE == 'auto' else cfg.EXEC_MODE,
+                      "host_issue_ms_per_step": round(t_issue_free * 1e3, 3), "host_issue_ms_per_step_queue_full": round(t_issue * 1e3, 3),
+                      "largest_mfma_launches": largest, "exec_mode": cfg.EXEC_MODE, "exec_mode_chosen": tr.exec_mode_chosen()[0] if cfg.EXEC_MODE == 'auto' else cfg.EXEC_MODE,
                       "exec_mode_timings_ms": {k: round(v * 1e3, 3) for k, v in tr.exec_mode_chosen()[1].items()},
                       "losses_d_g_c": [round(v, 4) for v in losses], "classes": classes}), flush=True)
 
