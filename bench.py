@@ -150,7 +150,7 @@ def measured_traffic():
     """HBM bytes of the dominant launch from the PMC passes stored under profiles/ (rocprofv3 cannot run inside this process).  The
     record names the kernel sources it was collected for (sha256 of the files in TRAFFIC_SOURCES): for any other source the
     figure is stale and `traffic` is null."""
-    for name in ('r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
+    for name in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
         tfile = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(tfile):
             continue

@@ -62,6 +62,18 @@ __device__ __forceinline__ u32x2 pack4_bf16(u32x4 v) {          // 4 fp32 -> 4 b
 #ifndef TG_PF_MID
 #define TG_PF_MID 2
 #endif
+#ifndef TG_PF_BF16_BIG
+#define TG_PF_BF16_BIG 1
+#endif
+#ifndef TG_PF_BF16_MID
+#define TG_PF_BF16_MID 2
+#endif
+#ifndef TG_PF_BF16_SMALL
+#define TG_PF_BF16_SMALL 2
+#endif
+#ifndef TG_WRITE_EARLY
+#define TG_WRITE_EARLY 0
+#endif
 #ifndef TG_PF_SMALL
 #define TG_PF_SMALL 2
 #endif
@@ -156,7 +168,9 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
   constexpr int AR = BM / 32, BR = BN / 32;   // 16-B loads per thread per tile
-  constexpr int PF = FIXUP ? 1 : (BM * BN >= 128 * 128 ? TG_PF_BIG : (BM * BN >= 128 * 64 ? TG_PF_MID : TG_PF_SMALL));      // register stages of the K pipeline (see the K loop)
+  // register stages of the K pipeline (see the K loop); bf16 operands have their own depths: a K-tile's MFMAs take a sixteenth of the fp32 time
+  constexpr int PF = FIXUP ? 1 : (BF16 ? (BM * BN >= 128 * 128 ? TG_PF_BF16_BIG : (BM * BN >= 128 * 64 ? TG_PF_BF16_MID : TG_PF_BF16_SMALL))
+                                       : (BM * BN >= 128 * 128 ? TG_PF_BIG : (BM * BN >= 128 * 64 ? TG_PF_MID : TG_PF_SMALL)));
   __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDT + 2 * BN * LDT + 4 * BM];
   float* As = smem;
   float* Bs = smem + 2 * BM * LDT;
@@ -401,9 +415,10 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       STAMP(ts0);
       issue(rs);                                         // stage rs went to LDS in the previous iteration (or in the prologue)
       STAMP(ts1);
+      if constexpr (TG_WRITE_EARLY && PF >= 2) sstore(buf ^ 1, (rs + 1) % PF);      // A/B: the next tile's LDS write under this tile's MFMAs (its loads are a whole iteration old)
       compute(buf);
       STAMP(ts2);
-      sstore(buf ^ 1, (rs + 1) % PF);
+      if constexpr (!(TG_WRITE_EARLY && PF >= 2)) sstore(buf ^ 1, (rs + 1) % PF);
       STAMP(ts3);
       __syncthreads();
       STAMP(ts4);

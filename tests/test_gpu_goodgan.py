@@ -205,7 +205,9 @@ def test_synchronised_iteration(data, prec, oracle_prec):
 # boundary differs by 2^-8 from then on (the floor is measured without a GPU in tests/test_oracle_goodgan.py::
 # test_bf16_rounding_amplifies_accumulation_noise).  Per variable: sampled elements within MX of the variable's largest gradient magnitude,
 # |g| and the 16 random-sign projections of the error within L2 of |g_ref| (a projection of an error vector e is ~N(0, |e|^2): 4 sigma).
-REF_TOL = dict(loss=2e-2, mx=0.25, l2=0.15, stat=2e-2, tie=0.05)
+# Measured on one MI355X (profiles/r04_svhn_bf16_step_ref.json), worst variable per solver run: D sampled elements 0.7 % / norm 0.4 %, G 3.9 % / 2.9 %,
+# C (ten batch norms between the rounding flips and the gradient) 14 % / 7.5 %; losses 2e-6 ... 2.5e-5 relative.  Tolerances = 2 - 2.5x that.
+REF_TOL = dict(loss=2e-4, stat=2e-2, tie=0.05, mx=dict(D=0.02, G=0.10, C=0.30), l2=dict(D=0.012, G=0.08, C=0.16))
 
 
 def test_svhn_bf16_solver_runs_at_the_reference_batch_sizes_against_the_fixture():
@@ -255,8 +257,8 @@ def test_svhn_bf16_solver_runs_at_the_reference_batch_sizes_against_the_fixture(
             e_mx = np.abs(got['sample'] - ref['sample']).max() / sc
             e_l2 = max(abs(got['l2'] - float(ref['l2'])) / n2, np.abs(got['proj'] - ref['proj']).max() / (4.0 * n2))
             worst['mx'], worst['l2'] = max(worst['mx'], e_mx), max(worst['l2'], e_l2)
-            assert e_mx <= REF_TOL['mx'], (phase, 'sampled elements', k, e_mx)
-            assert e_l2 <= REF_TOL['l2'], (phase, 'norm / projections', k, e_l2)
+            assert e_mx <= REF_TOL['mx'][phase], (phase, 'sampled elements', k, e_mx)
+            assert e_l2 <= REF_TOL['l2'][phase], (phase, 'norm / projections', k, e_l2)
         for key in fx:
             if key.startswith('stat/%s/' % phase):
                 k = key.split('/', 2)[2]
