@@ -103,6 +103,15 @@ int64_t tg_igemm_workspace_bytes(const tg_igemm_desc* descs, int n_desc, const i
  * (Model/Good_GAN_cifar10.py:296).  bias may be NULL. */
 int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* scratch, int64_t scratch_bytes,
                  void* stream);
+/* tg_igemm_f32 for a layer whose output goes straight into _conv_cond_concat (Model/modle_base.py:239-244, the discriminators' conv -> leaky
+ * relu -> concat(labels) pairs, Model/Good_GAN_cifar10.py:66-91): `out` IS the concatenated tensor [n_img,h_out,w_out,ld_out] — the launch stores
+ * its n_store channels as usual and ALSO writes channels [n_store, n_store + n_labels) of every output pixel = labels[image][0..n_labels) and zeros
+ * from there up to ld_out, so that no separate concat launch (tg_cond_concat_f32) reads and re-writes the activation.  One ungrouped sub-problem
+ * with os = 1, 4 | n_store, 4 | ld_out >= n_store + n_labels; labels: [n_img][n_labels] device floats.  Always the generic kernel. */
+int tg_igemm_labels_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, const float* labels, int n_labels, float* out,
+                        void* scratch, int64_t scratch_bytes, void* stream);
+int tg_igemm_labels_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, const float* labels, int n_labels, float* out,
+                         void* scratch, int64_t scratch_bytes, void* stream);
 /* up to 4 sub-problems in ONE launch (the output parities of a stride-2 transposed conv / strided-conv input-gradient):
  * same buffers, M, N and gathered tensor; each descriptor brings its own taps and output offsets. */
 int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out,

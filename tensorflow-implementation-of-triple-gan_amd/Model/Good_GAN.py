@@ -179,14 +179,19 @@ class Good_GAN(model_base.NN_Base):
                     h = self._add_noise(h, stddev=0.2)
                 return self._d_out(self._WN_dense(ops.cond_concat(h, y.t, y.c), 1, 'd_h5_wndense0', init=False, narrow=True), want_prob)
             image = self._drop_out(image, 0.2, True, fuse_next=True)                           # :126-165
-            h0 = self._WN_conv2d(self._conv_cond_concat(image, y), 32, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h0_wnconv0", activation=lre)
+            # (layers whose output goes straight into the next concat write that concatenation themselves: then_concat, ops.conv2d(concat=...))
+            h0 = self._WN_conv2d(self._conv_cond_concat(image, y), 32, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h0_wnconv0", activation=lre,
+                                 then_concat=y)
             h0 = self._WN_conv2d(self._conv_cond_concat(h0, y), 32, k_h=3, k_w=3, d_h=2, d_w=2, init=False, name="d_h0_wnconv1", activation=lre)
             h0 = self._drop_out(h0, 0.2, True, fuse_next=True)
-            h1 = self._WN_conv2d(self._conv_cond_concat(h0, y), 64, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h1_wnconv0", activation=lre)
+            h1 = self._WN_conv2d(self._conv_cond_concat(h0, y), 64, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h1_wnconv0", activation=lre,
+                                 then_concat=y)
             h1 = self._WN_conv2d(self._conv_cond_concat(h1, y), 64, k_h=3, k_w=3, d_h=2, d_w=2, init=False, name="d_h1_wnconv1", activation=lre)
             h1 = self._drop_out(h1, 0.2, True, fuse_next=True)
-            h2 = self._WN_conv2d(self._conv_cond_concat(h1, y), 128, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h2_wnconv0", activation=lre)
-            h2 = ops.cond_concat(h2, _twice(y), 2 * y.c)                                        # y is concatenated twice (:151-153)
+            y2 = _twice(y)
+            h2 = self._WN_conv2d(self._conv_cond_concat(h1, y), 128, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h2_wnconv0", activation=lre,
+                                 then_concat=(y2, 2 * y.c))
+            h2 = ops.cond_concat(h2, y2, 2 * y.c)                                               # y is concatenated twice (:151-153)
             h2 = self._WN_conv2d(h2, 128, k_h=3, k_w=3, d_h=1, d_w=1, init=False, name="d_h2_wnconv1", activation=lre)
             h3 = ops.global_avgpool_concat(h2, y.t, y.c)                                        # reduce_mean + concat y
             if self.config.MINIBATCH_DIS:                                                      # :159-162 (off in every config of the reference)

@@ -164,9 +164,12 @@ class Good_GAN_cifar10(model_base.NN_Base):
         with cx.variable_scope('discriminator'):
             image = self._drop_out(image, 0.2, True, fuse_next=True)
             h2 = image
-            for name, cout, stride, drop in self.D_CONVS:
+            for i, (name, cout, stride, drop) in enumerate(self.D_CONVS):
                 self._bucket_mark('discriminator', 'discriminator/%s/%s/kernel' % (name, name))
-                h2 = self._conv2d(self._conv_cond_concat(h2, y), cout, k_h=3, k_w=3, d_h=stride, d_w=stride, name=name, activation=lre)
+                # a layer whose output goes straight into the next _conv_cond_concat (no dropout in between) writes that concatenation itself
+                cat = y if (not drop and i + 1 < len(self.D_CONVS)) else None
+                h2 = self._conv2d(self._conv_cond_concat(h2, y), cout, k_h=3, k_w=3, d_h=stride, d_w=stride, name=name, activation=lre,
+                                  then_concat=cat)
                 if drop:
                     h2 = self._drop_out(_dense_view(h2), 0.2, True, fuse_next=True)
             assert h2.pending is None, "a dropout behind the last convolution has no concat to fuse into"

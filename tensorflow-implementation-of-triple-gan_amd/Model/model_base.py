@@ -25,6 +25,13 @@ def _act_of(fn):
     return a
 
 
+def _cat_of(then_concat):
+    """(label tensor, number of label channels) of a `then_concat=` argument: a label Act, such a tuple, or None."""
+    if then_concat is None or isinstance(then_concat, tuple):
+        return then_concat
+    return (then_concat.t, then_concat.c)
+
+
 class NN_Base(object):
     def __init__(self, batch_norm_decay=0.9, batch_norm_epsilon=1e-5):
         self._batch_norm_decay = batch_norm_decay
@@ -70,9 +77,11 @@ class NN_Base(object):
                               n_store_ld=(output_size, output_size) if narrow else None)
 
     def _conv2d(self, input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, kernel_initializer=None, name="conv2d",
-                activation=None, bn_segments=None):
+                activation=None, bn_segments=None, then_concat=None):
         """tf.layers.conv2d 'same' + bias (Model/modle_base.py:157-168).  bn_segments (extension): a training-mode _batch_norm_contrib over
-        these application segments follows directly — its statistics pass is taken in this layer's launch (ops.conv2d(bn_stats=True))."""
+        these application segments follows directly — its statistics pass is taken in this layer's launch (ops.conv2d(bn_stats=True)).
+        then_concat (extension): the label Act a _conv_cond_concat right behind this layer will append — the launch writes the concatenated
+        tensor itself (ops.conv2d(concat=...)) and that _conv_cond_concat becomes a view."""
         assert k_h == k_w and d_h == d_w
         cx = ctx()
         act, alpha = _act_of(activation)
@@ -80,7 +89,8 @@ class NN_Base(object):
             tr = cx.trains()
             return ops.conv2d(input_, cx.var('kernel'), cx.var('bias'), output_dim, k_h, d_h, 'SAME', act=act, alpha=alpha,
                               kernel_grad=cx.var_grad('kernel') if tr else None, bias_grad=cx.var_grad('bias') if tr else None,
-                              segments=bn_segments if bn_segments else None, bn_stats=bn_segments is not None)
+                              segments=bn_segments if bn_segments else None, bn_stats=bn_segments is not None,
+                              concat=_cat_of(then_concat))
 
     def _deconv2d(self, input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, name="deconv2d", use_bias=True,
                   kernel_initializer=None, activation=None, narrow=False):
@@ -120,8 +130,9 @@ class NN_Base(object):
                               bias_grad=cx.var_grad('b') if tr else None, n_store_ld=(output_size, output_size) if narrow else None)
 
     def _WN_conv2d(self, input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, padding='SAME', init_scale=1.0, init=False, name="conv2d",
-                   activation=None):
-        """g * conv(x, l2_normalize(V,[0,1,2])) + b (modle_base.py:75-108)."""
+                   activation=None, then_concat=None):
+        """g * conv(x, l2_normalize(V,[0,1,2])) + b (modle_base.py:75-108).  then_concat (extension): as in _conv2d — (label tensor, count) or a
+        label Act the _conv_cond_concat / cond_concat right behind this layer appends."""
         assert k_h == k_w and d_h == d_w
         cx = ctx()
         act, alpha = _act_of(activation)
@@ -129,7 +140,7 @@ class NN_Base(object):
             tr = cx.trains()
             return ops.conv2d(input_, cx.var('V'), cx.var('b'), int(output_dim), k_h, d_h, padding, act=act, alpha=alpha,
                               wn=(cx.var('g'), cx.var_grad('g') if tr else None), kernel_grad=cx.var_grad('V') if tr else None,
-                              bias_grad=cx.var_grad('b') if tr else None)
+                              bias_grad=cx.var_grad('b') if tr else None, concat=_cat_of(then_concat))
 
     def _WN_deconv2d(self, input_, output_dim, k_h=3, k_w=3, d_h=2, d_w=2, padding='SAME', init_scale=1.0, init=False, name="deconv2d",
                      activation=None, narrow=False):

@@ -128,6 +128,10 @@ struct IgemmParams {
                                   // dy * ymul (a batch norm's backward statistics, tg_igemm_bnbwdstat_*); 1 = the stored value is v = act(acc + bias) and colsum is [nseg][2][c_out]: sums of v and of v*v
                                   // (statistics of a batch norm behind the layer, tg_igemm_bnstat_*)
   int nseg, seg_rows[8];
+  // tg_igemm_labels_*: a _conv_cond_concat follows (Model/modle_base.py:239-244) — the output buffer is the concatenated tensor and the workgroups of
+  // the last column tile also write channels [lab_c0, lab_c0 + lab_n) = the image's label vector and zeros from there up to ld_out
+  const float* lab;
+  int lab_n, lab_c0;
   // ---- work units (tg::igemm_schedule, geom.cpp).  A unit is one output tile over a K range; tiles whose K range is cut into ks > 1
   // units leave raw partial accumulators in `ws` and are finished by the fix-up launch (same kernel, FIXUP = true).
   int n_units;                    // grid of the main launch
@@ -669,6 +673,28 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       }
     }
   }
+  if (p.lab != nullptr && nt == p.n_tiles - 1 && wn0 == 0) {
+    // the label channels and the channel padding of the concatenated tensor: lane = output pixel, the two lane halves alternate 16-byte groups
+    const int hw = d.h_v * d.w_v;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int rl = wm0 + mi * 32 + col;
+      const uint32_t ro = t_ob[rl];
+      const bool live = !(ro & OOB_OFF);
+      const float* lrow = p.lab + (int64_t)((m0 + rl) / hw) * p.lab_n;
+      for (int c4 = p.lab_c0 + 4 * half; c4 < d.ld_out; c4 += 8) {
+        float va[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ch = c4 + e - p.lab_c0;
+          va[e] = (live && ch < p.lab_n) ? lrow[ch] : 0.f;
+        }
+        const u32x4 pk = {__builtin_bit_cast(uint32_t, va[0]), __builtin_bit_cast(uint32_t, va[1]), __builtin_bit_cast(uint32_t, va[2]),
+                          __builtin_bit_cast(uint32_t, va[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_o, live ? ro + (uint32_t)c4 * 4u : OOB_OFF, 0, 0);
+      }
+    }
+  }
 #ifdef TG_STAMP
   {
     unsigned long long t_epi1;
@@ -1007,14 +1033,22 @@ static int head_tail(const tg_igemm_desc* descs, int n_desc, const int32_t* seg_
 
 static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, const float* w, const float* bias, float* out, void* stream,
                       double* colsum, const int32_t* seg_rows, int nseg, bool bf16 = false, const float* ymul = nullptr, int ymul_act = 0,
-                      float ymul_alpha = 0.f, void* scratch = nullptr, int64_t scratch_bytes = 0, int stat2 = 0) {
+                      float ymul_alpha = 0.f, void* scratch = nullptr, int64_t scratch_bytes = 0, int stat2 = 0, const float* lab = nullptr,
+                      int lab_n = 0) {
   TG_REQUIRE(descs && n_desc >= 1 && n_desc <= MAX_SUB, "igemm: n_desc=%d out of range", n_desc);
   TG_REQUIRE(in && w && out, "igemm: null buffer");
+  if (lab) {
+    const tg_igemm_desc* e = &descs[0];
+    TG_REQUIRE(n_desc == 1 && !colsum && e->n_group == 0 && e->os_x == 1 && e->os_y == 1 && lab_n >= 1 && (e->n_store & 3) == 0 && (e->ld_out & 3) == 0 &&
+               e->ld_out >= e->n_store + lab_n,
+               "igemm_labels: needs one ungrouped sub-problem with os = 1, 4 | n_store, 4 | ld_out and ld_out >= n_store + n_labels (n_store %d, ld_out %d, n_labels %d)",
+               e->n_store, e->ld_out, lab_n);
+  }
   // A 3x3 layer of the halo kernel's shape whose launch does not fill whole rounds of one workgroup per CU (conv3x3_bf16.hip): the leading
   // images that do go to that kernel, the few left over to the generic one — two launches over disjoint image ranges of the same buffers
   // (the column sums of both accumulate into the same per-segment accumulators).
   HeadTail ht;
-  if (const int head = head_tail(descs, n_desc, seg_rows, nseg, colsum != nullptr, bf16, &ht)) {
+  if (const int head = lab ? 0 : head_tail(descs, n_desc, seg_rows, nseg, colsum != nullptr, bf16, &ht)) {
     const int64_t per_img = (int64_t)descs[0].h_in * descs[0].w_in;
     int rc = igemm_impl(&ht.dh, 1, in, w, bias, out, stream, colsum, colsum ? ht.seg_h : nullptr, ht.nh, bf16, ymul, ymul_act, ymul_alpha, scratch, scratch_bytes, stat2);
     if (rc != TG_OK) return rc;
@@ -1028,6 +1062,7 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
   p.colsum = colsum; p.nseg = nseg;
   p.ymul = ymul; p.ymul_act = ymul_act; p.ymul_alpha = ymul_alpha;
   p.stat2 = stat2;
+  p.lab = lab; p.lab_n = lab_n; p.lab_c0 = descs[0].n_store;
   for (int i = 0; i < 8; ++i) p.seg_rows[i] = (seg_rows && i < nseg) ? seg_rows[i] : 0;
   const tg_igemm_desc* d = &descs[0];
   // sub-problems longest first: workgroups are dispatched in index order, so the 9-tap parity of a 5x5 s2 transposed
@@ -1073,7 +1108,7 @@ static int igemm_impl(const tg_igemm_desc* descs, int n_desc, const float* in, c
   const double flops = 2.0 * p.M * d->c_out * taps * d->ld_in;
   const double bytes = 4.0 * ((double)p.M * d->ld_in + (double)p.M * d->n_store * n_desc + (double)d->c_out * taps * d->ld_in);
   hipStream_t s = tg::as_stream(stream);
-  const bool halo = tg::conv3x3_bf16_applicable(descs, n_desc, seg_rows, colsum ? nseg : 0, bf16);      // the classifier's 3x3 layers: halo-tiled kernel (both operand types)
+  const bool halo = !lab && tg::conv3x3_bf16_applicable(descs, n_desc, seg_rows, colsum ? nseg : 0, bf16);      // the classifier's 3x3 layers: halo-tiled kernel (both operand types)
   // tile choice by the quantisation cost model of geom.cpp (tg::igemm_pick_tile; also behind tg_igemm_tile / tg_igemm_colsum_supported)
   int bm = 0, bn = 0;
   tg::IgemmSched sc;
@@ -1134,6 +1169,18 @@ extern "C" int tg_igemm_multi_f32(const tg_igemm_desc* descs, int n_desc, const 
 extern "C" int tg_igemm_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, float* out, void* scratch,
                             int64_t scratch_bytes, void* stream) {
   return igemm_impl(d, 1, in, w, bias, out, stream, nullptr, nullptr, 0, false, nullptr, 0, 0.f, scratch, scratch_bytes);
+}
+
+extern "C" int tg_igemm_labels_f32(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, const float* labels, int n_labels, float* out,
+                                   void* scratch, int64_t scratch_bytes, void* stream) {
+  TG_REQUIRE(labels != nullptr, "igemm_labels: null labels");
+  return igemm_impl(d, 1, in, w, bias, out, stream, nullptr, nullptr, 0, false, nullptr, 0, 0.f, scratch, scratch_bytes, 0, labels, n_labels);
+}
+
+extern "C" int tg_igemm_labels_bf16(const tg_igemm_desc* d, const float* in, const float* w, const float* bias, const float* labels, int n_labels, float* out,
+                                    void* scratch, int64_t scratch_bytes, void* stream) {
+  TG_REQUIRE(labels != nullptr, "igemm_labels: null labels");
+  return igemm_impl(d, 1, in, w, bias, out, stream, nullptr, nullptr, 0, true, nullptr, 0, 0.f, scratch, scratch_bytes, 0, labels, n_labels);
 }
 
 // scratch a launch of these descriptors can use: the larger of the halo kernel's packed bf16 filter (REQUIRED by such a launch) and the

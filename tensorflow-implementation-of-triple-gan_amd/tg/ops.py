@@ -14,7 +14,9 @@ _BNBWDSTAT = _os.environ.get('TG_BN_BWD_STAT_FUSE', '1') != '0'   # A/B switch: 
 _BNACT = _os.environ.get('TG_BN_ACT_FUSE', '1') != '0'      # A/B switch: activation derivative + bias gradient folded into the batch-norm backward pass
 _NARROW = _os.environ.get('TG_NARROW_DECONV', '1') != '0'     # A/B switch of csrc/narrow.hip (the generator's image layer, backward)
 _ACTSUM = _os.environ.get('TG_ACTSUM', '1') != '0'      # A/B switch of the input-gradient + activation-derivative + column-sum fusion
-_MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_igemm_actsum_f32', 'tg_igemm_bnstat_f32', 'tg_igemm_bnbwdstat_f32', 'tg_wgrad_f32')
+_MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_igemm_actsum_f32', 'tg_igemm_bnstat_f32', 'tg_igemm_bnbwdstat_f32', 'tg_wgrad_f32',
+             'tg_igemm_labels_f32')
+_CONCAT_FUSE = _os.environ.get('TG_CONCAT_FUSE', '1') != '0'     # A/B switch: conv -> cond_concat pairs written by the convolution's own epilogue (tg_igemm_labels_*)
 
 
 def _call(name, *args):
@@ -125,13 +127,16 @@ def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst, wn=None, defer=Tru
 # ------------------------------------------------------------------ conv / dense (plain and weight-normalised)
 
 def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=None, mobn=None, segments=None,
-           train=True, kernel_grad=None, bias_grad=None, n_store_ld=None, bn_stats=False):
+           train=True, kernel_grad=None, bias_grad=None, n_store_ld=None, bn_stats=False, concat=None):
     """y = act(conv(x, W) + bias)   or, with wn=(g, g_grad) and mobn=(b, b_grad, pop_mean):
        W = g V/||V||; y = act(conv(x, W) - mean_seg + b)            (Model/nn.py:469-520,525-589).
     kernel: HWIO tensor [k,k,c_in,c_out] (flat).  Dense layers are k = 1 on [n,1,1,c].
     n_store_ld: (n_store, ld_out) override for narrow outputs (D's logit).
     bn_stats: a training-mode batch norm over `segments` follows directly — its sum / sum-of-squares pass is taken in this launch's
-    epilogue (tg_igemm_bnstat_*) and left in y.bn_sums for batch_norm_train."""
+    epilogue (tg_igemm_bnstat_*) and left in y.bn_sums for batch_norm_train.
+    concat: (label tensor [n, ncls], ncls) — a cond_concat with these labels follows directly (the discriminators' conv -> leaky relu -> concat
+    pairs): the launch writes into the concatenated tensor's buffer and appends the label channels itself (tg_igemm_labels_*); the handle
+    returned still describes the c_out convolution channels, y.labels tells cond_concat that its work is done."""
     cx = ctx()
     assert x.ld % 32 == 0, "conv input must be channel-padded to 32"
     c_in, ci_p, co_p = x.c, x.ld, pad32(c_out)
@@ -171,7 +176,10 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
             if cx._prep_rec is not None and w_hwio is not None and not cx.use_side_stream:
                 cx._prep_rec.append(dict(key=key, kernel=kernel, g=wn[0] if wn is not None else None, scale=scale, w_oti=w_oti, w_hwio=w_hwio,
                                          t=t, a=c_in, b=c_out, a_pad=ci_p, b_pad=co_p, bump=cx.counter - c_before))
-    if n_store_ld is None:
+    fuse_cat = (_CONCAT_FUSE and concat is not None and mobn is None and not bn_stats and n_store_ld is None and c_out == co_p)
+    if fuse_cat:
+        n_store, ld_out = c_out, pad32(c_out + concat[1])
+    elif n_store_ld is None:
         n_store, ld_out = c_out, co_p
     else:
         n_store, ld_out = n_store_ld
@@ -193,6 +201,9 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
         bsum, zd = cx.zscratch('bn64', 32 * len(seg_rows) * c_out)     # the batch norm's buffer: 8 replicas x nseg x 2 x c doubles
         _call('tg_igemm_bnstat_f32', d, x.ptr, _p(w_oti), _p(bias), y.ptr, seg_array(seg_rows), len(seg_rows), _p(bsum), zd, cx.stream)
         y.bn_sums = (bsum, tuple(seg_rows))
+    elif fuse_cat:
+        _call('tg_igemm_labels_f32', d, x.ptr, _p(w_oti), _p(bias), _p(concat[0]), concat[1], y.ptr, cx.stream)
+        y.labels = (concat[0].data_ptr(), concat[1])
     else:
         _call('tg_igemm_f32', d, x.ptr, _p(w_oti), (_p(bias) if mobn is None else None), y.ptr, cx.stream)
     if mobn is not None and not fused:
@@ -525,6 +536,16 @@ def cond_concat(x, y_onehot_t, ncls):
     """concat([x, y*ones], 3), output channel-padded to 32 (Model/modle_base.py:239-244)."""
     cx = ctx()
     ld = pad32(x.c + ncls)
+    if x.labels is not None and x.labels == (y_onehot_t.data_ptr(), ncls) and x.ld == ld and x.pending is None:
+        # the producing convolution already wrote this concatenation into its own (wide) buffer: the same storage, seen with the label channels
+        out = Act(x.t, x.n, x.h, x.w, x.c + ncls, ld, requires_grad=x.requires_grad)
+        if cx.tape is not None and x.requires_grad:
+            def bwd_alias():                     # the convolution's backward reads its gradient through (pointer, channel stride): no copy
+                g = out.grad
+                x.grad = Act(g.t, x.n, x.h, x.w, x.c, g.ld)
+                x.grad.contribs = 1
+            cx.record(bwd_alias)
+        return out
     mask_t, mscale = None, 1.0
     if x.pending is not None:                    # a deferred dropout in front (scale_mask(defer=True)): one launch for both
         x, mask_t, mscale = x.pending

@@ -27,7 +27,7 @@ class Act(object):
     """Handle of an NHWC activation buffer: logical shape [n,h,w,c], channel stride ld >= c
     (channels c..ld are zero when the buffer feeds an MFMA kernel)."""
     __slots__ = ('t', 'n', 'h', 'w', 'c', 'ld', 'grad', 'requires_grad', 'strided_grad_ok', 'grad_sink', 'grad_fused', 'pending', 'bias_sink',
-                 'grad_is_dpre', 'bn_sums', 'bn_bwd_sink', 'bn_bwd_sums', 'contribs')
+                 'grad_is_dpre', 'bn_sums', 'bn_bwd_sink', 'bn_bwd_sums', 'contribs', 'labels')
 
     def __init__(self, t, n, h, w, c, ld, requires_grad=False):
         self.t, self.n, self.h, self.w, self.c, self.ld = t, n, h, w, c, ld
@@ -41,6 +41,7 @@ class Act(object):
         self.bn_sums = None               # (fp64 sums buffer, seg_rows): the producing convolution took the batch-norm statistics of this tensor
         self.bn_bwd_sink = None           # (batch norm's input Act, seg_rows): this tensor is a training-mode batch norm's output — the launch that
         self.bn_bwd_sums = None           # produces its gradient can take the backward statistics (sum dy, sum dy*x) and leaves the buffer here
+        self.labels = None                # (label tensor address, n labels): the producing convolution wrote the cond_concat behind it into this buffer
         self.contribs = 0                 # on a GRADIENT handle: how many backward closures have written into it (Context.grad_of) — the fused
                                           # backward paths above are only valid for exactly one
         self.pending = None               # (source Act, keep-mask, scale): a dropout the NEXT op applies in its own launch (ops.scale_mask(defer=True));

@@ -397,3 +397,38 @@ def test_narrow_transposed_conv_backward_on_the_vector_alus(n, h, w, cin, cout):
     lib.call('tg_deconv5x5s2_narrow_wgrad_f32', lib.ptr(dyd), co_p, lib.ptr(xd), ci_p, n, h, w, cout, cin, ci_p, lib.ptr(ws), lib.ptr(dwd), st)
     close(dwd.cpu().numpy().reshape(wt.shape), T.conv2d_transpose_bwd_filter(f8(x), f8(dy), wt.shape),
           T.conv2d_transpose_bwd_filter(np.abs(f8(x)), np.abs(f8(dy)), wt.shape))
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("n,h,cin,cout,s", [(5, 16, 42, 32, 1), (3, 16, 42, 64, 2), (7, 8, 74, 128, 1), (130, 8, 138, 128, 1)])
+def test_conv_writes_the_cond_concat_behind_it(n, h, cin, cout, s, prec):
+    """tg_igemm_labels_*: conv -> bias -> leaky relu whose output buffer IS the tensor _conv_cond_concat would build (Model/modle_base.py:239-244,
+    the discriminators' conv -> concat pairs): channels [cout, cout + 10) = the image's label vector, zeros up to the 32-padded stride, written by
+    the workgroups of the last column tile; the convolution channels as tg_igemm_* writes them.  Against oracle conv + conv_cond_concat; the
+    130-image case has several column tiles per row tile and tiles cut along K (the fix-up launch runs the same epilogue)."""
+    lib, geom = _tg()
+    q = lambda a: _q(prec, a)
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    lab = rng.random((n, 10)).astype(np.float32)                     # soft labels (the C-update feeds the classifier's one-hots, any vector works)
+    ci_p, co_p, ld = geom.pad32(cin), geom.pad32(cout), geom.pad32(cout + 10)
+    y_ref = T.lrelu(T.conv2d(f8(q(x)), f8(q(wt)), (s, s), 'SAME') + f8(bias))
+    y_abs = T.conv2d(np.abs(f8(q(x))), np.abs(f8(q(wt))), (s, s), 'SAME') + np.abs(f8(bias))
+    cat_ref = T.conv_cond_concat(y_ref, f8(lab))
+    ho = y_ref.shape[1]
+    w_oti = np.zeros((co_p, 9, ci_p), np.float32)
+    w_oti[:cout, :, :cin] = wt.reshape(9, cin, cout).transpose(2, 0, 1)
+    xd, wd, bd, ld_ = dev(padc(x, ci_p)), dev(w_oti), dev(padc(bias, co_p)), dev(lab)
+    yd = torch.full((n, ho, ho, ld), 7.0, device='cuda')
+    d = geom.conv_fwd(n, h, h, ci_p, co_p, 3, s, 'SAME', ld_out=ld, n_store=cout, act='lrelu')
+    lib.call_igemm("tg_igemm_labels_" + prec, d, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(ld_), 10, lib.ptr(yd), lib.cur_stream())
+    y = yd.cpu().numpy()
+    close(y[..., :cout], y_ref, y_abs)
+    np.testing.assert_array_equal(y[..., cout:cout + 10], cat_ref[..., cout:].astype(np.float32))      # the labels, bit for bit
+    assert (y[..., cout + 10:] == 0).all()
+    # too narrow an output stride for the labels is refused
+    bad = geom.conv_fwd(n, h, h, ci_p, co_p, 3, s, 'SAME', ld_out=co_p, n_store=cout, act='lrelu')
+    with pytest.raises(lib.TgError, match='igemm_labels'):
+        lib.call_igemm("tg_igemm_labels_" + prec, bad, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(ld_), 10, lib.ptr(yd), lib.cur_stream())
