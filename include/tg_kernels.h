@@ -324,6 +324,12 @@ int tg_mobn_finalize_f32(const float* sums, const int32_t* seg_rows, int nseg, i
  * y = act(x - pop_mean + b) when sums is NULL (evaluation).  c <= 512, c % 4 == 0. */
 int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows, int nseg, const double* sums, const float* b, float* pop_mean,
                       float decay, int act, float alpha, void* stream);
+/* tg_mobn_apply_f32 AND the max-pool 2x2 + dropout behind the layer (Model/Good_GAN_cifar10.py:121-124,140-143: conv1_3 / conv2_3 -> tf.nn.max_pool ->
+ * tf.layers.dropout) in one pass over the convolution's raw output x [n,h,w,c]: x = act(x - mean + b) in place (the backward pass reads it) and
+ * out [n,h/2,w/2,c] = max over the 2x2 window of that * mask * mscale (mask NULL: no dropout — evaluation).  Segments must be whole images. */
+int tg_mobn_apply_pool_f32(float* x, int ld, int n, int h, int w, int c, const int32_t* seg_rows, int nseg, const double* sums, const float* b,
+                           float* pop_mean, float decay, int act, float alpha, float* out, int ld_out, const float* mask, int ld_mask, float mscale,
+                           void* stream);
 /* fused backward of mean-only BN + nonlinearity: dx = dy*act'(yact) - mean_seg(dy*act'(yact)), db[k] = sum over all rows
  * (db may be NULL).  sums: scratch of 8*nseg*c doubles (8 replicas of the accumulators; sums_zeroed as colsum_zeroed above).  Two launches (sums with fp64 atomics, apply).  c <= 512, c % 4 == 0;
  * segments of any size. */

@@ -197,12 +197,13 @@ class Good_GAN_cifar10(model_base.NN_Base):
             x = ops.im2col3x3_add(inp, noise)
             for i, (name, cout, pad, pool) in enumerate(self.C_CONVS):
                 self._bucket_mark('classifier', 'classifier/%s/V' % name)
-                x = nn.conv2d_WN(x, num_filters=cout, name=name, pad=pad, filter_size=[1, 1] if i == 0 else [3, 3], **kw)
-                if pool:                                                             # max_pool_k + dropout_k (:123-124,142-143)
+                then_pool = None
+                if pool:                                                             # max_pool_k + dropout_k (:123-124,142-143): in the layer's apply launch
                     mask = None
                     if is_training:
-                        mask = cx.rng.keep_mask(cx, 'drop' + name[4], x.rows // 4 * x.c, 0.5)
-                    x = ops.maxpool2_dropout(x, mask, 2.0)
+                        mask = cx.rng.keep_mask(cx, 'drop' + name[4], x.rows // 4 * cout, 0.5)
+                    then_pool = (mask, 2.0)
+                x = nn.conv2d_WN(x, num_filters=cout, name=name, pad=pad, filter_size=[1, 1] if i == 0 else [3, 3], then_pool=then_pool, **kw)
             x = nn.NiN_WN(x, num_units=256, name='NiN1', **kw)
             x = nn.NiN_WN(x, num_units=128, name='NiN2', **kw)
             x = ops.global_maxpool(x)                                                # tf.layers.max_pooling2d(pool 6) named avg_pool_0

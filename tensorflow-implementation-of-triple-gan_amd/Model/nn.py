@@ -81,8 +81,15 @@ def batch_norm_impl(x, is_conv_out=True, deterministic=False, decay=0.9, name='B
 
 
 def _wn_layer(x, num_out, k, pad, stride, nonlinearity, init_scale, init, use_weight_normalization, use_batch_normalization,
-              use_mean_only_batch_normalization, deterministic, segments, init_eps):
-    """body shared by conv2d_WN (k x k) and dense_WN (k = 1 on [n,1,1,c]): every flag combination of nn.py:476-518,529-570."""
+              use_mean_only_batch_normalization, deterministic, segments, init_eps, then_pool=None):
+    """body shared by conv2d_WN (k x k) and dense_WN (k = 1 on [n,1,1,c]): every flag combination of nn.py:476-518,529-570.
+    then_pool (extension): (keep-mask or None, 1/keep) of a max-pool 2x2 + dropout right behind the layer — the pooled activation is returned;
+    on the weight-norm + mean-only-BN path with a fusable nonlinearity the pooling rides in the layer's apply launch (ops.conv2d(pool=...))."""
+    if then_pool is not None and not (use_weight_normalization and use_mean_only_batch_normalization and not init
+                                      and (_tg_act(nonlinearity) is not None or nonlinearity is None)):
+        y = _wn_layer(x, num_out, k, pad, stride, nonlinearity, init_scale, init, use_weight_normalization, use_batch_normalization,
+                      use_mean_only_batch_normalization, deterministic, segments, init_eps)
+        return ops.maxpool2_dropout(y, then_pool[0], then_pool[1])
     cx = ctx()
     if use_weight_normalization and use_batch_normalization:
         raise ValueError("use_weight_normalization with use_batch_normalization: the reference creates no bias for that combination and "
@@ -109,7 +116,7 @@ def _wn_layer(x, num_out, k, pad, stride, nonlinearity, init_scale, init, use_we
                            train=not deterministic, kernel_grad=gr('V'))
             return nonlinearity(y)
         return ops.conv2d(x, V, None, num_out, k, stride, pad, wn=(g, gr('g')), mobn=(b, gr('b'), pop), segments=segments,
-                          train=not deterministic, kernel_grad=gr('V'), **fuse)
+                          train=not deterministic, kernel_grad=gr('V'), pool=then_pool, **fuse)
     if use_weight_normalization:                       # just weight normalisation: g*conv(x, V/||V||) + b
         y = ops.conv2d(x, V, b, num_out, k, stride, pad, wn=(g, gr('g')), kernel_grad=gr('V'), bias_grad=gr('b'), **fuse)
         return y if (a or nonlinearity is None) else nonlinearity(y)
@@ -123,12 +130,13 @@ def _wn_layer(x, num_out, k, pad, stride, nonlinearity, init_scale, init, use_we
 
 def conv2d_WN(x, num_filters, filter_size=[3, 3], pad='SAME', stride=[1, 1], nonlinearity=None, init_scale=1., init=False,
               use_weight_normalization=False, use_batch_normalization=False, use_mean_only_batch_normalization=False,
-              deterministic=False, name='', segments=None):
-    """Model/nn.py:469-520: W = g*l2_normalize(V,[0,1,2]); conv; mean-only BN (+b) | +b | batch_norm_impl; nonlinearity."""
+              deterministic=False, name='', segments=None, then_pool=None):
+    """Model/nn.py:469-520: W = g*l2_normalize(V,[0,1,2]); conv; mean-only BN (+b) | +b | batch_norm_impl; nonlinearity.
+    segments, then_pool: extensions (see _wn_layer)."""
     assert filter_size[0] == filter_size[1] and stride[0] == stride[1]
     with ctx().variable_scope(name):
         return _wn_layer(x, num_filters, filter_size[0], pad, stride[0], nonlinearity, init_scale, init, use_weight_normalization,
-                         use_batch_normalization, use_mean_only_batch_normalization, deterministic, segments, 1e-8)
+                         use_batch_normalization, use_mean_only_batch_normalization, deterministic, segments, 1e-8, then_pool=then_pool)
 
 
 def dense_WN(x, num_units, nonlinearity=None, init_scale=1., init=False, use_weight_normalization=False,

@@ -256,6 +256,59 @@ __global__ void __launch_bounds__(256) mobn_apply(float* __restrict__ x, int ld,
   }
 }
 
+// mobn_apply + tf.nn.max_pool 2x2 + dropout behind it (Model/Good_GAN_cifar10.py:121-124,140-143) in ONE pass over the convolution's raw output:
+// x = act(x + shift) in place (kept: the backward pass reads it) and pooled[n, h/2, w/2, c] = max over the 2x2 window of it, times the keep-mask and
+// 1/keep.  A workgroup owns one pooled row of one image (two image rows: inside one application segment); workgroup 0 applies the sequential
+// pop_mean updates as in mobn_apply.  Saves the max-pool launch's read of the activated tensor.
+__global__ void __launch_bounds__(256) mobn_apply_pool(float* __restrict__ x, int ld, int h, int w, int c, SegTable st, const double* __restrict__ sums,
+                                                       const float* __restrict__ b, float* __restrict__ pop, float decay, int act, float alpha,
+                                                       float* __restrict__ out, int ld_out, const float* __restrict__ mask, int ld_m, float mscale) {
+  __shared__ float shift[512];
+  const int ho = h >> 1, wo = w >> 1;
+  const int img = blockIdx.x / ho, oy = blockIdx.x - img * ho;
+  const int64_t row0 = ((int64_t)img * h + 2 * oy) * w;                 // first pixel row of this workgroup
+  int seg = 0;
+  int64_t acc_rows = st.rows[0];
+  while (seg < st.nseg - 1 && row0 >= acc_rows) acc_rows += st.rows[++seg];
+  for (int k = threadIdx.x; k < c; k += 256) {
+    const float bb = b ? b[k] : 0.f;
+    shift[k] = sums ? bb - (float)(sums[(int64_t)seg * c + k] / (double)st.rows[seg]) : bb - pop[k];
+  }
+  if (blockIdx.x == 0 && sums) {
+    for (int k = threadIdx.x; k < c; k += 256) {
+      float pm = pop[k];
+      for (int s = 0; s < st.nseg; ++s) pm = pm * decay + (float)(sums[(int64_t)s * c + k] / (double)st.rows[s]) * (1.f - decay);
+      pop[k] = pm;
+    }
+  }
+  __syncthreads();
+  const int c4 = c >> 2;
+  for (int i = threadIdx.x; i < wo * c4; i += 256) {
+    const int ox = i / c4, cg = i - ox * c4;
+    float* p = x + (row0 + 2 * ox) * ld + cg * 4;
+    float4 v[4] = {*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + ld), *reinterpret_cast<const float4*>(p + (int64_t)w * ld),
+                   *reinterpret_cast<const float4*>(p + (int64_t)(w + 1) * ld)};
+    const float s0 = shift[cg * 4], s1 = shift[cg * 4 + 1], s2 = shift[cg * 4 + 2], s3 = shift[cg * 4 + 3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q].x = tgd::act(v[q].x + s0, act, alpha); v[q].y = tgd::act(v[q].y + s1, act, alpha);
+      v[q].z = tgd::act(v[q].z + s2, act, alpha); v[q].w = tgd::act(v[q].w + s3, act, alpha);
+    }
+    *reinterpret_cast<float4*>(p) = v[0];
+    *reinterpret_cast<float4*>(p + ld) = v[1];
+    *reinterpret_cast<float4*>(p + (int64_t)w * ld) = v[2];
+    *reinterpret_cast<float4*>(p + (int64_t)(w + 1) * ld) = v[3];
+    float4 m = make_float4(fmaxf(fmaxf(v[0].x, v[1].x), fmaxf(v[2].x, v[3].x)), fmaxf(fmaxf(v[0].y, v[1].y), fmaxf(v[2].y, v[3].y)),
+                           fmaxf(fmaxf(v[0].z, v[1].z), fmaxf(v[2].z, v[3].z)), fmaxf(fmaxf(v[0].w, v[1].w), fmaxf(v[2].w, v[3].w)));
+    const int64_t pix = ((int64_t)img * ho + oy) * wo + ox;
+    if (mask) {
+      const float4 k = *reinterpret_cast<const float4*>(mask + pix * ld_m + cg * 4);
+      m.x *= k.x * mscale; m.y *= k.y * mscale; m.z *= k.z * mscale; m.w *= k.w * mscale;
+    }
+    *reinterpret_cast<float4*>(out + pix * ld_out + cg * 4) = m;
+  }
+}
+
 // Mean-only-BN backward in two launches: (1) sums[seg][c] += sum_rows dy*act'(y) (one fp64 atomic per column per workgroup),
 // (2) dpre = dy*act'(y) - sums[seg]/rows_seg with the shift derived in LDS; workgroup 0 writes db = sum_seg sums.
 __global__ void __launch_bounds__(256) mobn_bwd_sums(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y, int rows, int c,
@@ -932,6 +985,26 @@ int tg_mobn_apply_f32(float* x, int ld, int rows, int c, const int32_t* seg_rows
   tg::ProfScope prof(tg::PC_NORM, 0, 8.0 * rows * c, s);
   hipLaunchKernelGGL(mobn_apply, dim3(seg_chunks(st, 32)), dim3(256), 0, s, x, ld, rows, c, st, sums, b, pop_mean, decay, act, alpha);
   TG_CHECK_LAUNCH("mobn_apply");
+  return TG_OK;
+}
+
+int tg_mobn_apply_pool_f32(float* x, int ld, int n, int h, int w, int c, const int32_t* seg_rows, int nseg, const double* sums, const float* b,
+                           float* pop_mean, float decay, int act, float alpha, float* out, int ld_out, const float* mask, int ld_mask, float mscale,
+                           void* stream) {
+  SegTable st;
+  const int rows = n * h * w;
+  int rc = make_segs(st, seg_rows, nseg, rows);
+  if (rc != TG_OK) return rc;
+  TG_REQUIRE(x && out && pop_mean && n > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0 && c > 0 && c <= 512 && c % 4 == 0 && ld % 4 == 0 && c <= ld &&
+             ld_out % 4 == 0 && c <= ld_out && (!mask || (ld_mask % 4 == 0 && c <= ld_mask)), "mobn_apply_pool: c=%d ld=%d ld_out=%d h=%d w=%d unsupported", c, ld,
+             ld_out, h, w);
+  for (int i = 0; i < nseg; ++i)
+    TG_REQUIRE(seg_rows[i] % (h * w) == 0, "mobn_apply_pool: segment %d (%d rows) is not a whole number of %dx%d images", i, seg_rows[i], h, w);
+  hipStream_t s = tg::as_stream(stream);
+  tg::ProfScope prof(tg::PC_NORM, 0, 4.0 * rows * c * 2.25, s);
+  hipLaunchKernelGGL(mobn_apply_pool, dim3(n * (h / 2)), dim3(256), 0, s, x, ld, h, w, c, st, sums, b, pop_mean, decay, act, alpha, out, ld_out, mask, ld_mask,
+                     mscale);
+  TG_CHECK_LAUNCH("mobn_apply_pool");
   return TG_OK;
 }
 

@@ -16,6 +16,7 @@ _NARROW = _os.environ.get('TG_NARROW_DECONV', '1') != '0'     # A/B switch of cs
 _ACTSUM = _os.environ.get('TG_ACTSUM', '1') != '0'      # A/B switch of the input-gradient + activation-derivative + column-sum fusion
 _MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_igemm_actsum_f32', 'tg_igemm_bnstat_f32', 'tg_igemm_bnbwdstat_f32', 'tg_wgrad_f32',
              'tg_igemm_labels_f32')
+_POOL_FUSE = _os.environ.get('TG_POOL_FUSE', '1') != '0'         # A/B switch: mean-only-BN apply + max-pool 2x2 + dropout in one launch (tg_mobn_apply_pool_f32)
 _CONCAT_FUSE = _os.environ.get('TG_CONCAT_FUSE', '1') != '0'     # A/B switch: conv -> cond_concat pairs written by the convolution's own epilogue (tg_igemm_labels_*)
 
 
@@ -127,7 +128,7 @@ def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst, wn=None, defer=Tru
 # ------------------------------------------------------------------ conv / dense (plain and weight-normalised)
 
 def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=None, mobn=None, segments=None,
-           train=True, kernel_grad=None, bias_grad=None, n_store_ld=None, bn_stats=False, concat=None):
+           train=True, kernel_grad=None, bias_grad=None, n_store_ld=None, bn_stats=False, concat=None, pool=None):
     """y = act(conv(x, W) + bias)   or, with wn=(g, g_grad) and mobn=(b, b_grad, pop_mean):
        W = g V/||V||; y = act(conv(x, W) - mean_seg + b)            (Model/nn.py:469-520,525-589).
     kernel: HWIO tensor [k,k,c_in,c_out] (flat).  Dense layers are k = 1 on [n,1,1,c].
@@ -136,7 +137,9 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     epilogue (tg_igemm_bnstat_*) and left in y.bn_sums for batch_norm_train.
     concat: (label tensor [n, ncls], ncls) — a cond_concat with these labels follows directly (the discriminators' conv -> leaky relu -> concat
     pairs): the launch writes into the concatenated tensor's buffer and appends the label channels itself (tg_igemm_labels_*); the handle
-    returned still describes the c_out convolution channels, y.labels tells cond_concat that its work is done."""
+    returned still describes the c_out convolution channels, y.labels tells cond_concat that its work is done.
+    pool: (keep-mask tensor or None, 1/keep) — tf.nn.max_pool 2x2 + dropout follow directly (the classifier's conv1_3 / conv2_3): returns the POOLED
+    activation; on the fused mean-only-BN path the apply pass and the pooling are one launch (tg_mobn_apply_pool_f32)."""
     cx = ctx()
     assert x.ld % 32 == 0, "conv input must be channel-padded to 32"
     c_in, ci_p, co_p = x.c, x.ld, pad32(c_out)
@@ -187,6 +190,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     d = geom.conv_fwd(x.n, x.h, x.w, ci_p, co_p, k, stride, padding, ld_out=ld_out, n_store=n_store, act=fused_act, alpha=alpha)
     y = cx.new_act(x.n, d.h_out, d.w_out, c_out, ld_out, requires_grad=needs_w or needs_x)
     y.strided_grad_ok = True
+    pooled = None
     seg_rows = _segs(y, segments)
     fused = (mobn is not None and train and c_out == co_p and c_out <= 512 and stride == 1 and geom.colsum_supported(d, seg_rows))
     if fused:
@@ -194,8 +198,13 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
         b, b_grad, pop = mobn
         sums, zd = cx.zscratch('cs64', 2 * len(seg_rows) * c_out)     # fp64 accumulators
         _call('tg_igemm_colsum_f32', d, x.ptr, _p(w_oti), y.ptr, seg_array(seg_rows), len(seg_rows), _p(sums), zd, cx.stream)
-        _call('tg_mobn_apply_f32', y.ptr, y.ld, y.rows, c_out, seg_array(seg_rows), len(seg_rows), _p(sums), _p(b), _p(pop), 0.9, ACT[act],
-              alpha, cx.stream)
+        if _POOL_FUSE and pool is not None and y.h % 2 == 0 and y.w % 2 == 0 and all(r % (y.h * y.w) == 0 for r in seg_rows):
+            pooled = cx.new_act(y.n, y.h // 2, y.w // 2, c_out, co_p, requires_grad=needs_w or needs_x)
+            _call('tg_mobn_apply_pool_f32', y.ptr, y.ld, y.n, y.h, y.w, c_out, seg_array(seg_rows), len(seg_rows), _p(sums), _p(b), _p(pop), 0.9, ACT[act],
+                  alpha, pooled.ptr, pooled.ld, _p(pool[0]), c_out, pool[1], cx.stream)
+        else:
+            _call('tg_mobn_apply_f32', y.ptr, y.ld, y.rows, c_out, seg_array(seg_rows), len(seg_rows), _p(sums), _p(b), _p(pop), 0.9, ACT[act],
+                  alpha, cx.stream)
     elif (_BNSTAT and bn_stats and mobn is None and act in (None, 'relu', 'lrelu') and c_out == co_p == ld_out and len(seg_rows) <= 8
           and geom.colsum_supported(d, seg_rows)):
         bsum, zd = cx.zscratch('bn64', 32 * len(seg_rows) * c_out)     # the batch norm's buffer: 8 replicas x nseg x 2 x c doubles
@@ -218,7 +227,7 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
               None, _p(shift), ACT[act], alpha, cx.stream)
 
     if not (needs_w or needs_x):
-        return y
+        return _pool_after(cx, y, pooled, pool)
     if mobn is not None and train and act is not None and c_out == co_p and c_out <= 512 and len(seg_rows) <= 8 and ld_out == co_p:
         y.grad_sink = (act, alpha, tuple(seg_rows))      # see Act.grad_sink
     if mobn is None and act in ('relu', 'lrelu') and needs_w and bias_grad is not None and c_out == co_p == ld_out:
@@ -302,7 +311,18 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
                 _call('tg_igemm_multi_f32', dds, len(dds), _p(dpre), _p(w_hwio), None, gx.ptr, cx.stream)
 
     cx.record(bwd)
-    return y
+    return _pool_after(cx, y, pooled, pool)
+
+
+def _pool_after(cx, y, pooled, pool):
+    """what conv2d returns: y, or — conv2d(pool=...) — the max-pooled, dropped-out activation: made by the fused apply launch (`pooled`) or by the
+    stand-alone pooling op; its backward closure goes on the tape behind the convolution's."""
+    if pool is None:
+        return y
+    if pooled is None:
+        return maxpool2_dropout(y, pool[0], pool[1])
+    _record_maxpool_bwd(cx, y, pooled, pool[0], pool[1])
+    return pooled
 
 
 def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None, narrow_out=False, wn=None):
@@ -592,6 +612,12 @@ def maxpool2_dropout(y, mask_t, mscale):
     cx = ctx()
     out = cx.new_act(y.n, y.h // 2, y.w // 2, y.c, y.ld, requires_grad=y.requires_grad)
     _call('tg_maxpool2_fwd_f32', y.ptr, y.ld, out.ptr, out.ld, _p(mask_t), y.c, mscale, y.n, y.h, y.w, y.c, cx.stream)
+    _record_maxpool_bwd(cx, y, out, mask_t, mscale)
+    return out
+
+
+def _record_maxpool_bwd(cx, y, out, mask_t, mscale):
+    """backward closure of max-pool 2x2 + dropout from y to out (shared by maxpool2_dropout and the fused apply + pool launch of conv2d)."""
     if cx.tape is not None and y.requires_grad:
         def bwd():
             fresh = y.grad is None
@@ -609,7 +635,6 @@ def maxpool2_dropout(y, mask_t, mscale):
                 _call('tg_maxpool2_bwd_f32', out.grad.ptr, out.grad.ld, _p(mask_t), y.c, mscale, y.ptr, y.ld, gy.ptr, gy.ld, y.n, y.h, y.w,
                       y.c, cx.stream)
         cx.record(bwd)
-    return out
 
 
 def global_maxpool(x):

@@ -670,3 +670,45 @@ def test_batch_norm_backward_statistics_in_the_epilogue_of_the_launch_that_produ
         tol = 3e-5 * scale if nm == 'dy' else 3e-4 * max(1.0, np.abs(b).max())
         assert np.abs(a - b).max() <= tol, (nm, np.abs(a - b).max(), tol)
     assert not (out['fused'][1] == 7.0).any()
+
+
+@pytest.mark.parametrize("train,use_mask", [(True, True), (True, False), (False, False)])
+def test_mobn_apply_and_max_pool_in_one_launch(train, use_mask):
+    """tg_mobn_apply_pool_f32 (the classifier's conv1_3 / conv2_3 -> max_pool -> dropout, Model/Good_GAN_cifar10.py:121-124,140-143) against
+    tg_mobn_apply_f32 followed by tg_maxpool2_fwd_f32 on the same inputs: the same float operations in the same order — bit-identical activated
+    tensor, pooled tensor and pop_mean, for a training pass over three application segments and for evaluation (sums = NULL, no mask)."""
+    import ctypes as C
+    lib = _lib()
+    rng = np.random.default_rng(41)
+    segs, h, w, c = [3, 2, 4], 8, 16, 128
+    n = sum(segs)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    pop0 = rng.standard_normal(c).astype(np.float32)
+    mask = (rng.random((n, h // 2, w // 2, c)) < 0.5).astype(np.float32)
+    seg_rows = [s * h * w for s in segs]
+    sa = (C.c_int32 * len(segs))(*seg_rows)
+    sums = np.concatenate([x[o:o + s].astype(np.float64).sum(axis=(0, 1, 2)) for o, s in zip(np.cumsum([0] + segs[:-1]), segs)])
+    sd = torch.from_numpy(sums).cuda() if train else None
+    bd, md = dev(b), dev(mask) if use_mask else None
+    xa, pa = dev(x), dev(pop0)
+    oa = torch.full((n, h // 2, w // 2, c), 7.0, device='cuda')
+    lib.call('tg_mobn_apply_f32', lib.ptr(xa), c, n * h * w, c, sa, len(segs), lib.ptr(sd), lib.ptr(bd), lib.ptr(pa), 0.9, lib.ACT['lrelu'], 0.2, st())
+    lib.call('tg_maxpool2_fwd_f32', lib.ptr(xa), c, lib.ptr(oa), c, lib.ptr(md), c, 2.0, n, h, w, c, st())
+    xb, pb = dev(x), dev(pop0)
+    ob = torch.full((n, h // 2, w // 2, c), 7.0, device='cuda')
+    lib.call('tg_mobn_apply_pool_f32', lib.ptr(xb), c, n, h, w, c, sa, len(segs), lib.ptr(sd), lib.ptr(bd), lib.ptr(pb), 0.9, lib.ACT['lrelu'], 0.2,
+             lib.ptr(ob), c, lib.ptr(md), c, 2.0, st())
+    np.testing.assert_array_equal(xb.cpu().numpy(), xa.cpu().numpy())
+    np.testing.assert_array_equal(ob.cpu().numpy(), oa.cpu().numpy())
+    np.testing.assert_array_equal(pb.cpu().numpy(), pa.cpu().numpy())
+    if train:                                                  # and it is the oracle's arithmetic, not merely the same as the other kernel
+        o, ref = 0, []
+        for s_ in segs:
+            ref.append(T.lrelu(x[o:o + s_].astype(np.float64) - x[o:o + s_].astype(np.float64).mean(axis=(0, 1, 2)) + b, 0.2))
+            o += s_
+        np.testing.assert_allclose(xb.cpu().numpy(), np.concatenate(ref), rtol=1e-5, atol=1e-5)
+    bad = (C.c_int32 * 2)(5 * h * w - 7, 4 * h * w + 7)        # a segment boundary inside an image is refused
+    with pytest.raises(lib.TgError, match='whole number'):
+        lib.call('tg_mobn_apply_pool_f32', lib.ptr(xb), c, n, h, w, c, bad, 2, lib.ptr(sd), lib.ptr(bd), lib.ptr(pb), 0.9, lib.ACT['lrelu'], 0.2,
+                 lib.ptr(ob), c, lib.ptr(md), c, 2.0, st())

@@ -20,8 +20,12 @@ CSV = sys.argv[2] if len(sys.argv) > 2 else None
 p32 = geom.pad32
 
 
-def timeit(fn, iters=30):
-    for _ in range(5):
+ITERS = int(os.environ.get('TG_SHAPES_ITERS', '30'))          # PMC passes (tools/pmc_step_shapes.sh) use few
+
+
+def timeit(fn, iters=None):
+    iters = ITERS if iters is None else iters
+    for _ in range(min(5, iters)):
         fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
