@@ -71,6 +71,12 @@ __device__ __forceinline__ u32x2 pack4_bf16(u32x4 v) {          // 4 fp32 -> 4 b
 #ifndef TG_PF_BF16_SMALL
 #define TG_PF_BF16_SMALL 2
 #endif
+#ifndef TG_PF_ROLE
+#define TG_PF_ROLE 3                  // register stages of the loader waves of a role-split launch
+#endif
+#ifndef TG_ROLE_MASK
+#define TG_ROLE_MASK 0                // which tile classes launch role-split: 1 = smaller than 128x64, 2 = 128x64 / 64x128 (the 128x128 tile needs > 128 registers)
+#endif
 #ifndef TG_WRITE_EARLY
 #define TG_WRITE_EARLY 0
 #endif
@@ -167,13 +173,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // FIXUP = true: the second launch of a schedule with cut tiles — no K loop: the accumulators are the sum (in K-segment order, so
 // deterministic) of the partials the main launch left in p.ws, then the SAME epilogue.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool COLSUM, bool BF16, bool FIXUP = false>
-__global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
+// ROLE = true (round 4): 512 threads — waves 0-3 are CONSUMERS (LDS fragment reads + MFMAs only, one barrier per K-tile), waves 4-7 LOADERS
+// (global -> registers -> LDS, the waits for memory, the tap arithmetic) which leave after the K loop; prologue tables, the partial-sum
+// store and every epilogue are the 256-thread code of the consumers, unchanged.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool COLSUM, bool BF16, bool FIXUP = false, bool ROLE = false>
+__global__ void __launch_bounds__(ROLE ? 512 : 256, 2) igemm_f32_kernel(IgemmParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(!(ROLE && FIXUP), "the fix-up launch has no K loop");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
   constexpr int AR = BM / 32, BR = BN / 32;   // 16-B loads per thread per tile
   // register stages of the K pipeline (see the K loop); bf16 operands have their own depths: a K-tile's MFMAs take a sixteenth of the fp32 time
-  constexpr int PF = FIXUP ? 1 : (BF16 ? (BM * BN >= 128 * 128 ? TG_PF_BF16_BIG : (BM * BN >= 128 * 64 ? TG_PF_BF16_MID : TG_PF_BF16_SMALL))
+  constexpr int PF = FIXUP ? 1 : ROLE ? TG_PF_ROLE : (BF16 ? (BM * BN >= 128 * 128 ? TG_PF_BF16_BIG : (BM * BN >= 128 * 64 ? TG_PF_BF16_MID : TG_PF_BF16_SMALL))
                                        : (BM * BN >= 128 * 128 ? TG_PF_BIG : (BM * BN >= 128 * 64 ? TG_PF_MID : TG_PF_SMALL)));
   __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDT + 2 * BN * LDT + 4 * BM];
   float* As = smem;
@@ -247,7 +257,9 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   }
   __syncthreads();
 
-  const int seg = tid & 7, lrow = tid >> 3;
+  const int ltid = ROLE ? (tid & 255) : tid;            // ROLE: the loader waves (tid 256 ...) carry the 256-thread load mapping
+  const bool is_loader = ROLE && tid >= 256;
+  const int seg = ltid & 7, lrow = ltid >> 3;
   int abase[AR], ay[AR], ax[AR];
 #pragma unroll
   for (int j = 0; j < AR; ++j) {
@@ -358,10 +370,12 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     c0 += BK;
     if (c0 == ld_in) { c0 = 0; ++tap; if (issued < it1) set_tap(tap); }
   };
+  if (!ROLE || is_loader) {
 #pragma unroll
-  for (int rs = 0; rs < PF; ++rs)
-    if (it0 + rs < it1) issue(rs);
-  sstore(0, 0);
+    for (int rs = 0; rs < PF; ++rs)
+      if (it0 + rs < it1) issue(rs);
+    sstore(0, 0);
+  }
   __syncthreads();
 
 #ifdef TG_STAMP
@@ -410,6 +424,38 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
     }
   };
   int it = it0;
+  if constexpr (ROLE) {
+    if (is_loader) {
+      // loaders: the K pipeline without the MFMAs — tile it+1 goes to the other LDS buffer while the consumers multiply tile it
+      while (issued + PF <= it1) {
+#pragma unroll
+        for (int rs = 0; rs < PF; ++rs) {
+          issue(rs);
+          sstore(buf ^ 1, (rs + 1) % PF);
+          __syncthreads();
+          buf ^= 1;
+        }
+        it += PF;
+      }
+      for (; it < it1; it += PF) {
+#pragma unroll
+        for (int rs = 0; rs < PF; ++rs) {
+          if (it + rs < it1) {
+            if (issued < it1) issue(rs);
+            if (it + rs + 1 < it1) sstore(buf ^ 1, (rs + 1) % PF);
+            __syncthreads();
+            buf ^= 1;
+          }
+        }
+      }
+      return;                                            // (a finished wave no longer counts at the workgroup's barriers)
+    }
+    for (; it < it1; ++it) {                             // consumers
+      compute(buf);
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
   // steady state, PF iterations at a time, each issuing one tile UNCONDITIONALLY: straight-line code, so the wait in front of the LDS
   // write of stage rs + 1 is a counted one (the PF - 1 younger tiles stay in flight) — with a branch around the issue the compiler has to
   // assume the youngest loads are the ones it needs and drains the queue every iteration
@@ -447,6 +493,7 @@ __global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
       }
     }
   }
+  }  // !ROLE
 #ifdef TG_STAMP
   {
     unsigned long long t_end;
@@ -992,12 +1039,14 @@ int check_desc(const tg_igemm_desc* d) {
 template <int BM, int BN, int WM_, int WN_>
 static void launch_igemm(IgemmParams& p, hipStream_t s, bool bf16) {
   const dim3 grid(p.n_units);               // one workgroup per work unit (tg::igemm_schedule); the last column tile may overhang: filter rows >= c_out read zeros / unused data, stores are masked by n_store
+  constexpr bool ROLE = ((TG_ROLE_MASK & 1) && BM * BN < 128 * 64) || ((TG_ROLE_MASK & 2) && BM * BN == 128 * 64);
+  constexpr int NT = ROLE ? 512 : 256;
   if (bf16) {
-    if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, true>), grid, dim3(256), 0, s, p);
+    if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, true, false, ROLE>), grid, dim3(NT), 0, s, p);
+    else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, true, false, ROLE>), grid, dim3(NT), 0, s, p);
   } else {
-    if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, false>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, false>), grid, dim3(256), 0, s, p);
+    if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, false, false, ROLE>), grid, dim3(NT), 0, s, p);
+    else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, false, false, ROLE>), grid, dim3(NT), 0, s, p);
   }
   if (p.n_fix > 0) {                        // tiles that were cut along K: add their partial sums up, then the usual epilogue (operand type plays no part)
     if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, false, true>), dim3(p.n_fix), dim3(256), 0, s, p);

@@ -8,7 +8,8 @@ sys.path.insert(0, os.path.join(ROOT, "tensorflow-implementation-of-triple-gan_a
 from tg import lib, geom
 L = lib.load()
 L.tg_debug_read_stamps.argtypes = [C.POINTER(C.c_uint64)]
-for name, N, hw, ci, co in (("d_conv0 32ch", 100, 32, 32, 32), ("d_conv2 64->64 @16", 100, 16, 64, 64), ("d_conv4 96->128 @8", 250, 8, 96, 128),
+for name, N, hw, ci, co in (("d_conv0 32ch", 100, 32, 32, 32), ("d_conv2 64->64 @16", 100, 16, 64, 64), ("d_conv4 96->128 @8", 250, 8, 96, 128), ("d_conv5 160->128 @8 n=100 (200 units)", 100, 8, 160, 128),
+                            ("d_conv5 160->128 @8 n=250 (500 units)", 250, 8, 160, 128), ("conv3-like 256->512 @8 n=250 SAME via generic (2000 units)", 250, 8, 256, 512),
                             ("c_conv1_2 (reference)", 250, 32, 128, 128)):
     x = torch.randn(N, hw, hw, ci, device='cuda'); w = torch.randn(co, 9, ci, device='cuda') * 0.05
     d = geom.conv_fwd(N, hw, hw, ci, co, 3, 1, 'SAME'); y = torch.empty(N, hw, hw, co, device='cuda')
