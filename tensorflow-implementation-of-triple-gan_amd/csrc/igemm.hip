@@ -71,17 +71,8 @@ __device__ __forceinline__ u32x2 pack4_bf16(u32x4 v) {          // 4 fp32 -> 4 b
 #ifndef TG_PF_BF16_SMALL
 #define TG_PF_BF16_SMALL 2
 #endif
-#ifndef TG_PF_ROLE
-#define TG_PF_ROLE 3                  // register stages of the loader waves of a role-split launch
-#endif
-#ifndef TG_ROLE_MASK
-#define TG_ROLE_MASK 0                // which tile classes launch role-split: 1 = smaller than 128x64, 2 = 128x64 / 64x128 (the 128x128 tile needs > 128 registers)
-#endif
 #ifndef TG_INTERLEAVE
 #define TG_INTERLEAVE 1               // A/B: one memory instruction behind every MFMA in the K loop of the one-accumulator tiles (see the K loop)
-#endif
-#ifndef TG_WRITE_EARLY
-#define TG_WRITE_EARLY 0
 #endif
 #ifndef TG_PF_SMALL
 #define TG_PF_SMALL 2
@@ -176,21 +167,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // FIXUP = true: the second launch of a schedule with cut tiles — no K loop: the accumulators are the sum (in K-segment order, so
 // deterministic) of the partials the main launch left in p.ws, then the SAME epilogue.
-// ROLE = true (round 4): 512 threads — waves 0-3 are CONSUMERS (LDS fragment reads + MFMAs only, one barrier per K-tile), waves 4-7 LOADERS
-// (global -> registers -> LDS, the waits for memory, the tap arithmetic) which leave after the K loop; prologue tables, the partial-sum
-// store and every epilogue are the 256-thread code of the consumers, unchanged.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool COLSUM, bool BF16, bool FIXUP = false, bool ROLE = false>
-__global__ void __launch_bounds__(ROLE ? 512 : 256, 2) igemm_f32_kernel(IgemmParams p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool COLSUM, bool BF16, bool FIXUP = false>
+__global__ void __launch_bounds__(256, 2) igemm_f32_kernel(IgemmParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-  static_assert(!(ROLE && FIXUP), "the fix-up launch has no K loop");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
   constexpr int AR = BM / 32, BR = BN / 32;   // 16-B loads per thread per tile
   // register stages of the K pipeline (see the K loop); bf16 operands have their own depths: a K-tile's MFMAs take a sixteenth of the fp32 time
-  // IL3 (TG_INTERLEAVE = 2): the interleaved K-tile schedule of the one-accumulator tiles over THREE LDS buffers and three register stages, so that
-  // the first fragments of tile it+1 are read BEFORE the barrier that ends tile it (they were written a whole iteration earlier)
-  constexpr bool IL3 = TG_INTERLEAVE >= 2 && MI == 1 && NI == 1 && !BF16 && !FIXUP && !ROLE && (AR + BR) <= 5;
-  constexpr int NBUF = IL3 ? 3 : 2;
-  constexpr int PF = FIXUP ? 1 : ROLE ? TG_PF_ROLE : IL3 ? 3 : (BF16 ? (BM * BN >= 128 * 128 ? TG_PF_BF16_BIG : (BM * BN >= 128 * 64 ? TG_PF_BF16_MID : TG_PF_BF16_SMALL))
+  constexpr int NBUF = 2;                     // LDS buffers per operand
+  constexpr int PF = FIXUP ? 1 : (BF16 ? (BM * BN >= 128 * 128 ? TG_PF_BF16_BIG : (BM * BN >= 128 * 64 ? TG_PF_BF16_MID : TG_PF_BF16_SMALL))
                                        : (BM * BN >= 128 * 128 ? TG_PF_BIG : (BM * BN >= 128 * 64 ? TG_PF_MID : TG_PF_SMALL)));
   __shared__ __attribute__((aligned(16))) float smem[NBUF * BM * LDT + NBUF * BN * LDT + 4 * BM];
   float* As = smem;
@@ -264,9 +248,7 @@ __global__ void __launch_bounds__(ROLE ? 512 : 256, 2) igemm_f32_kernel(IgemmPar
   }
   __syncthreads();
 
-  const int ltid = ROLE ? (tid & 255) : tid;            // ROLE: the loader waves (tid 256 ...) carry the 256-thread load mapping
-  const bool is_loader = ROLE && tid >= 256;
-  const int seg = ltid & 7, lrow = ltid >> 3;
+  const int seg = tid & 7, lrow = tid >> 3;
   int abase[AR], ay[AR], ax[AR];
 #pragma unroll
   for (int j = 0; j < AR; ++j) {
@@ -380,90 +362,10 @@ __global__ void __launch_bounds__(ROLE ? 512 : 256, 2) igemm_f32_kernel(IgemmPar
 #ifdef TG_STAMP
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, acc_load = 0, acc_mfma = 0, acc_store = 0, acc_bar = 0, t_begin = 0;
 #endif
-  if constexpr (IL3) {
-    // ---- three-buffer interleaved pipeline.  Tile t lives in register stage and LDS buffer (t - it0) % 3.  Iteration `it` (buffer r): the 16
-    // dependent MFMAs of tile it, and behind them, one per MFMA: the fragments of groups 1..3, the loads of tile it+3 (stage r), the LDS writes
-    // of tile it+2 (buffer r+2, last read in iteration it-1), the first fragments of tile it+1 (buffer r+1, written in iteration it-1).
-    constexpr int NL = AR + BR;
 #pragma unroll
-    for (int rs = 0; rs < 3; ++rs)
-      if (it0 + rs < it1) issue(rs);
-    sstore(0, 0);
-    if (it0 + 1 < it1) sstore(1, 1);
-    __syncthreads();
-    f32x4 nfa = *reinterpret_cast<const f32x4*>(As + wm0 * LDT + frag);          // group 0 of tile it0
-    f32x4 nfb = *reinterpret_cast<const f32x4*>(Bs + wn0 * LDT + frag);
-    auto body = [&](const int r, const bool do_load, const bool do_write, const bool do_pref) __attribute__((always_inline)) {      // r: a constant at every call site
-      const int r1 = (r + 1) % 3, r2 = (r + 2) % 3;
-      const uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane(c0 * 4);
-      const uint32_t sw = (uint32_t)__builtin_amdgcn_readfirstlane((w_tap_off + c0) * 4);
-      const float* A = As + r * BM * LDT + wm0 * LDT + frag;
-      const float* B = Bs + r * BN * LDT + wn0 * LDT + frag;
-      const float* An = As + r1 * BM * LDT + wm0 * LDT + frag;
-      const float* Bn = Bs + r1 * BN * LDT + wn0 * LDT + frag;
-      float* wa = As + r2 * BM * LDT + lrow * LDT + seg * 4;
-      float* wb = Bs + r2 * BN * LDT + lrow * LDT + seg * 4;
-      f32x4 fa[2], fb[2];
-      fa[0] = nfa; fb[0] = nfb;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int g = k >> 2, sft = k & 3, cur = g & 1;
-        if (COLSUM) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][sft], fb[cur][sft], acc[0][0], 0, 0, 0);
-        else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][sft], fa[cur][sft], acc[0][0], 0, 0, 0);
-        if (sft == 0 && g < 3) fa[cur ^ 1] = *reinterpret_cast<const f32x4*>(A + (g + 1) * 8);
-        else if (sft == 1 && g < 3) fb[cur ^ 1] = *reinterpret_cast<const f32x4*>(B + (g + 1) * 8);
-        else {
-          const int j = (g < 3) ? 2 * g + (sft - 2) : 6 + sft;           // 0 .. 9 over the free slots (2,3,6,7,10,11,12..15)
-          if (j < NL) {
-            if (do_load) {
-              if (j < AR) ra[r][j < AR ? j : 0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, avoff[j < AR ? j : 0], sa, 0);
-              else rb[r][j >= AR ? j - AR : 0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wvoff[j >= AR ? j - AR : 0], sw, 0);
-            }
-          } else if (j < 2 * NL) {
-            const int q = j - NL;
-            if (do_write) {
-              if (q < AR) *reinterpret_cast<u32x4*>(wa + 32 * (q < AR ? q : 0) * LDT) = ra[r2][q < AR ? q : 0];
-              else *reinterpret_cast<u32x4*>(wb + 32 * (q >= AR ? q - AR : 0) * LDT) = rb[r2][q >= AR ? q - AR : 0];
-            }
-          } else if (j == 2 * NL) {
-            if (do_pref) nfa = *reinterpret_cast<const f32x4*>(An);
-          } else if (j == 2 * NL + 1) {
-            if (do_pref) nfb = *reinterpret_cast<const f32x4*>(Bn);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (2 * NL + 2 > 10 && do_pref) {                    // NL = 5 (128x32, 32x128): no slot left for the next tile's first fragments
-        nfa = *reinterpret_cast<const f32x4*>(An);
-        nfb = *reinterpret_cast<const f32x4*>(Bn);
-      }
-      if (do_load) {                                       // the cursor of the tile just issued (what issue() does behind its loads)
-        ++issued;
-        c0 += BK;
-        if (c0 == ld_in) { c0 = 0; ++tap; if (issued < it1) set_tap(tap); }
-      }
-      __syncthreads();
-    };
-    int it = it0;
-    while (issued + 3 <= it1) {                            // steady state: tiles it+3 .. it+5 exist — straight-line code, counted waits
-      body(0, true, true, true);
-      body(1, true, true, true);
-      body(2, true, true, true);
-      it += 3;
-    }
-    for (; it < it1; it += 3) {                            // drain: at most five iterations
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-        if (it + r < it1) body(r, it + r + 3 < it1, it + r + 2 < it1, it + r + 1 < it1);
-    }
-  } else {
-  if (!ROLE || is_loader) {
-#pragma unroll
-    for (int rs = 0; rs < PF; ++rs)
-      if (it0 + rs < it1) issue(rs);
-    sstore(0, 0);
-  }
+  for (int rs = 0; rs < PF; ++rs)
+    if (it0 + rs < it1) issue(rs);
+  sstore(0, 0);
   __syncthreads();
 
 #ifdef TG_STAMP
@@ -511,38 +413,6 @@ __global__ void __launch_bounds__(ROLE ? 512 : 256, 2) igemm_f32_kernel(IgemmPar
     }
   };
   int it = it0;
-  if constexpr (ROLE) {
-    if (is_loader) {
-      // loaders: the K pipeline without the MFMAs — tile it+1 goes to the other LDS buffer while the consumers multiply tile it
-      while (issued + PF <= it1) {
-#pragma unroll
-        for (int rs = 0; rs < PF; ++rs) {
-          issue(rs);
-          sstore(buf ^ 1, (rs + 1) % PF);
-          __syncthreads();
-          buf ^= 1;
-        }
-        it += PF;
-      }
-      for (; it < it1; it += PF) {
-#pragma unroll
-        for (int rs = 0; rs < PF; ++rs) {
-          if (it + rs < it1) {
-            if (issued < it1) issue(rs);
-            if (it + rs + 1 < it1) sstore(buf ^ 1, (rs + 1) % PF);
-            __syncthreads();
-            buf ^= 1;
-          }
-        }
-      }
-      return;                                            // (a finished wave no longer counts at the workgroup's barriers)
-    }
-    for (; it < it1; ++it) {                             // consumers
-      compute(buf);
-      __syncthreads();
-      buf ^= 1;
-    }
-  } else {
   // steady state, PF iterations at a time, each issuing one tile UNCONDITIONALLY: straight-line code, so the wait in front of the LDS
   // write of stage rs + 1 is a counted one (the PF - 1 younger tiles stay in flight) — with a branch around the issue the compiler has to
   // assume the youngest loads are the ones it needs and drains the queue every iteration
@@ -551,51 +421,65 @@ __global__ void __launch_bounds__(ROLE ? 512 : 256, 2) igemm_f32_kernel(IgemmPar
     // order — while MFMA k runs (64 cycles) the wave sits at MFMA k+1, so anything placed before or behind the chain is time the matrix pipe
     // idles when no second wave shares the SIMD (launches with at most one workgroup per CU: profiles/r04_stamp_small.txt).  Here every
     // memory instruction of the K-tile — six fragment reads, the AR + BR global loads of tile it+PF, the AR + BR LDS writes of tile it+1 —
-    // sits in its own slot BEHIND one MFMA (fenced, so that the compiler keeps it there) and issues in that MFMA's shadow.
+    // sits in its own slot BEHIND one MFMA (fenced, so that the compiler keeps it there) and issues in that MFMA's shadow
+    // (profiles/r04_interleave_ab.txt: -6.5 % over the generic launches of the step, -15 ... -18 % where one workgroup owns a CU).
     constexpr int NL = AR + BR;
-    while (issued + PF <= it1) {
+    // one K-tile; rs (register stage of the tile being loaded) is a constant at every call site.  do_load / do_write: the steady state passes
+    // true (straight-line code, counted waits), the drain what is left to load / to write
+    auto ktile = [&](const int rs, const bool do_load, const bool do_write) __attribute__((always_inline)) {
+      const int ws = (rs + 1) % PF;                       // register stage of tile it+1 (its loads are a whole iteration old)
+      const uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane(c0 * 4);
+      const uint32_t sw = (uint32_t)__builtin_amdgcn_readfirstlane((w_tap_off + c0) * 4);
+      const float* A = As + buf * BM * LDT + wm0 * LDT + frag;
+      const float* B = Bs + buf * BN * LDT + wn0 * LDT + frag;
+      float* wa = As + (buf ^ 1) * BM * LDT + lrow * LDT + seg * 4;
+      float* wb = Bs + (buf ^ 1) * BN * LDT + lrow * LDT + seg * 4;
+      f32x4 fa[2], fb[2];
+      fa[0] = *reinterpret_cast<const f32x4*>(A);
+      fb[0] = *reinterpret_cast<const f32x4*>(B);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int rs = 0; rs < PF; ++rs) {
-        constexpr int dummy = 0; (void)dummy;
-        const int ws = (rs + 1) % PF;                     // register stage of tile it+1 (its loads are a whole iteration old)
-        const uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane(c0 * 4);
-        const uint32_t sw = (uint32_t)__builtin_amdgcn_readfirstlane((w_tap_off + c0) * 4);
-        const float* A = As + buf * BM * LDT + wm0 * LDT + frag;
-        const float* B = Bs + buf * BN * LDT + wn0 * LDT + frag;
-        float* wa = As + (buf ^ 1) * BM * LDT + lrow * LDT + seg * 4;
-        float* wb = Bs + (buf ^ 1) * BN * LDT + lrow * LDT + seg * 4;
-        f32x4 fa[2], fb[2];
-        fa[0] = *reinterpret_cast<const f32x4*>(A);
-        fb[0] = *reinterpret_cast<const f32x4*>(B);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int g = k >> 2, sft = k & 3, cur = g & 1;
-          if (COLSUM) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][sft], fb[cur][sft], acc[0][0], 0, 0, 0);
-          else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][sft], fa[cur][sft], acc[0][0], 0, 0, 0);
-          // slot k: k = 4g, 4g+1 (g < 3): the fragments of group g+1; the other ten slots: NL loads, then NL LDS writes
-          if (sft == 0 && g < 3) fa[cur ^ 1] = *reinterpret_cast<const f32x4*>(A + (g + 1) * 8);
-          else if (sft == 1 && g < 3) fb[cur ^ 1] = *reinterpret_cast<const f32x4*>(B + (g + 1) * 8);
-          else {
-            const int j = (g < 3) ? 2 * g + (sft - 2) : 6 + sft;         // 0 .. 9 over the free slots (2,3,6,7,10,11,12..15)
-            if (j < NL) {
+      for (int k = 0; k < 16; ++k) {
+        const int g = k >> 2, sft = k & 3, cur = g & 1;
+        if (COLSUM) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][sft], fb[cur][sft], acc[0][0], 0, 0, 0);
+        else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][sft], fa[cur][sft], acc[0][0], 0, 0, 0);
+        // slot k: k = 4g, 4g+1 (g < 3): the fragments of group g+1; the other ten slots: NL loads, then NL LDS writes
+        if (sft == 0 && g < 3) fa[cur ^ 1] = *reinterpret_cast<const f32x4*>(A + (g + 1) * 8);
+        else if (sft == 1 && g < 3) fb[cur ^ 1] = *reinterpret_cast<const f32x4*>(B + (g + 1) * 8);
+        else {
+          const int j = (g < 3) ? 2 * g + (sft - 2) : 6 + sft;           // 0 .. 9 over the free slots (2,3,6,7,10,11,12..15)
+          if (j < NL) {
+            if (do_load) {
               if (j < AR) ra[rs][j < AR ? j : 0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, avoff[j < AR ? j : 0], sa, 0);
               else rb[rs][j >= AR ? j - AR : 0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wvoff[j >= AR ? j - AR : 0], sw, 0);
-            } else if (j < 2 * NL) {
-              const int q = j - NL;
+            }
+          } else if (j < 2 * NL) {
+            const int q = j - NL;
+            if (do_write) {
               if (q < AR) *reinterpret_cast<u32x4*>(wa + 32 * (q < AR ? q : 0) * LDT) = ra[ws][q < AR ? q : 0];
               else *reinterpret_cast<u32x4*>(wb + 32 * (q >= AR ? q - AR : 0) * LDT) = rb[ws][q >= AR ? q - AR : 0];
             }
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
-        ++issued;                                          // the cursor of the tile just issued (what issue() does behind its loads)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (do_load) {                                       // the cursor of the tile just issued (what issue() does behind its loads)
+        ++issued;
         c0 += BK;
         if (c0 == ld_in) { c0 = 0; ++tap; if (issued < it1) set_tap(tap); }
-        __syncthreads();
-        buf ^= 1;
       }
+      __syncthreads();
+      buf ^= 1;
+    };
+    while (issued + PF <= it1) {
+#pragma unroll
+      for (int rs = 0; rs < PF; ++rs) ktile(rs, true, true);
       it += PF;
+    }
+    for (; it < it1; it += PF) {                           // drain (and K ranges shorter than the pipeline)
+#pragma unroll
+      for (int rs = 0; rs < PF; ++rs)
+        if (it + rs < it1) ktile(rs, issued < it1, it + rs + 1 < it1);
     }
   }
   while (issued + PF <= it1) {
@@ -604,10 +488,9 @@ __global__ void __launch_bounds__(ROLE ? 512 : 256, 2) igemm_f32_kernel(IgemmPar
       STAMP(ts0);
       issue(rs);                                         // stage rs went to LDS in the previous iteration (or in the prologue)
       STAMP(ts1);
-      if constexpr (TG_WRITE_EARLY && PF >= 2) sstore(buf ^ 1, (rs + 1) % PF);      // A/B: the next tile's LDS write under this tile's MFMAs (its loads are a whole iteration old)
       compute(buf);
       STAMP(ts2);
-      if constexpr (!(TG_WRITE_EARLY && PF >= 2)) sstore(buf ^ 1, (rs + 1) % PF);
+      sstore(buf ^ 1, (rs + 1) % PF);
       STAMP(ts3);
       __syncthreads();
       STAMP(ts4);
@@ -632,8 +515,6 @@ __global__ void __launch_bounds__(ROLE ? 512 : 256, 2) igemm_f32_kernel(IgemmPar
       }
     }
   }
-  }  // !ROLE
-  }  // !IL3
 #ifdef TG_STAMP
   {
     unsigned long long t_end;
@@ -1179,14 +1060,12 @@ int check_desc(const tg_igemm_desc* d) {
 template <int BM, int BN, int WM_, int WN_>
 static void launch_igemm(IgemmParams& p, hipStream_t s, bool bf16) {
   const dim3 grid(p.n_units);               // one workgroup per work unit (tg::igemm_schedule); the last column tile may overhang: filter rows >= c_out read zeros / unused data, stores are masked by n_store
-  constexpr bool ROLE = ((TG_ROLE_MASK & 1) && BM * BN < 128 * 64) || ((TG_ROLE_MASK & 2) && BM * BN == 128 * 64);
-  constexpr int NT = ROLE ? 512 : 256;
   if (bf16) {
-    if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, true, false, ROLE>), grid, dim3(NT), 0, s, p);
-    else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, true, false, ROLE>), grid, dim3(NT), 0, s, p);
+    if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, true>), grid, dim3(256), 0, s, p);
   } else {
-    if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, false, false, ROLE>), grid, dim3(NT), 0, s, p);
-    else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, false, false, ROLE>), grid, dim3(NT), 0, s, p);
+    if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, false>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, false, false>), grid, dim3(256), 0, s, p);
   }
   if (p.n_fix > 0) {                        // tiles that were cut along K: add their partial sums up, then the usual epilogue (operand type plays no part)
     if (p.colsum) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM_, WN_, true, false, true>), dim3(p.n_fix), dim3(256), 0, s, p);
