@@ -153,3 +153,38 @@ def test_no_buffer_is_allocated_once_the_execution_mode_is_decided():
     assert tr.exec_mode_chosen()[0] in ('plan', 'graph')
     assert (len(tr.cx.buffers), torch.cuda.memory_allocated()) == settled
     assert all(np.isfinite(v) for v in tr.losses())
+
+
+def test_launch_plan_api_on_two_streams_and_its_error_report():
+    """include/tg_plan.h driven directly: two fills on two streams ordered by an event, replayed twice (also on other streams than the ones it
+    was recorded with); a recorded launch whose entry point refuses its arguments stops the replay and names the operation."""
+    import ctypes as C
+    import torch
+    from tg import lib, plan
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    a = torch.zeros(1 << 16, device='cuda')
+    b = torch.zeros(1 << 16, device='cuda')
+    ev = torch.cuda.Event()
+    ev.record(s0)                                        # creates the event's handle
+    p = plan.Plan([s0.cuda_stream, s1.cuda_stream])
+    p.add_launch('tg_fill_f32', (lib.ptr(a), 3.0, a.numel(), C.c_void_p(s0.cuda_stream)))
+    p.add_record(ev, s0.cuda_stream)
+    p.add_wait(s1.cuda_stream, ev)
+    p.add_launch('tg_copy2d_f32', (lib.ptr(a), a.numel(), lib.ptr(b), b.numel(), 1, a.numel(), C.c_void_p(s1.cuda_stream)))   # b = a, after the fill
+    assert len(p) == 4 and p.launches == 2
+    p.replay()
+    torch.cuda.synchronize()
+    assert float(b.min()) == 3.0 == float(b.max())
+    a.zero_(); b.zero_()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Stream(), torch.cuda.Stream()
+    p.replay([t0.cuda_stream, t1.cuda_stream])           # the slots are positions, not the recorded handles
+    torch.cuda.synchronize()
+    assert float(b.min()) == 3.0 == float(b.max())
+    bad = plan.Plan([s0.cuda_stream])
+    bad.add_launch('tg_fill_f32', (lib.ptr(a), 1.0, 16, C.c_void_p(s0.cuda_stream)))
+    bad.add_launch('tg_copy2d_f32', (None, 4, lib.ptr(b), 4, 1, 4, C.c_void_p(s0.cuda_stream)))            # a null source: refused by the entry point
+    with pytest.raises(lib.TgError, match=r'operation 1 \(tg_copy2d_f32\) failed: copy2d'):
+        bad.replay()
+    torch.cuda.synchronize()
+    assert float(a[:16].max()) == 1.0                    # the operation in front of the failing one was issued
