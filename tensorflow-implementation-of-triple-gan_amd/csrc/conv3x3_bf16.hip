@@ -63,6 +63,9 @@ __device__ unsigned long long tg_conv_stamps[8 * 64];
 #define LSTAMP(var) do {} while (0)
 #endif
 
+#ifndef TG_C3_PIPE
+#define TG_C3_PIPE 1                           // bf16 consumers: fragment reads software-pipelined behind the MFMAs (0 = the compiler's order; A/B builds)
+#endif
 #ifndef TG_ABL
 #define TG_ABL 0                               // timing ablations of conv3x3_pipe_kernel (tools only, results then wrong): 1 no stores, 8 half the halo loads, 16 half the filter loads, 32 no MFMAs
 #endif
@@ -418,6 +421,49 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
           const bool last_g = g == NG - 1;
           const bool more = !(last_g && last_c) || has_next;
           const unsigned char* B = Bs + bbuf * B_BYTES;
+          if constexpr (BF16 && TG_C3_PIPE) {
+            // A bf16 MFMA holds the pipe for 32 cycles and a wave issues in order: six fragment reads in front of every eight MFMAs left the
+            // pipe idle ~80 cycles per sub-step (stamps: 4 055 cycles per step outside the barriers against 3 072 of MFMAs).  Here the twelve
+            // (tap, k-slice) sub-steps of a step are one software pipeline over two fragment register sets: the six reads of sub-step
+            // i + 1 are issued one each behind the first six MFMAs of sub-step i (in the order their MFMAs need them), so only the first
+            // reads of a step — behind its barrier — are waited for.
+            int a_row[TPS][2], a_swz[TPS][2];
+#pragma unroll
+            for (int k = 0; k < TPS; ++k) {
+              const int tp = p.tap[TPS * g + k];
+              const int shift = (int)(int8_t)(tp >> 8) * HW_ + (int)(int8_t)tp;
+#pragma unroll
+              for (int mi = 0; mi < 2; ++mi) {
+                const int hp = a_hp[mi] + shift;
+                a_row[k][mi] = hp * 128;
+                a_swz[k][mi] = (hp >> 1) & 7;
+              }
+            }
+            bf16x8 fa[2][2], fb[2][4];
+            auto rd = [&](int i, int j, int set) {                // read j of sub-step i: a0, b0, b1, b2, b3, a1
+              const int k = i >> 2, s = i & 3;
+              if (j == 0 || j == 5) {
+                const int mi = j == 0 ? 0 : 1;
+                fa[set][mi] = *reinterpret_cast<const bf16x8*>(As + a_row[k][mi] + (((2 * s + half) ^ a_swz[k][mi]) << 4));
+              } else {
+                fb[set][j - 1] = *reinterpret_cast<const bf16x8*>(B + k * B_TAP + b_off[j - 1] + (((2 * s + half) ^ b_swz) << 4));
+              }
+            };
+#pragma unroll
+            for (int j = 0; j < 6; ++j) rd(0, j, 0);
+#pragma unroll
+            for (int i = 0; i < 4 * TPS; ++i) {
+#pragma unroll
+              for (int m = 0; m < 8; ++m) {
+                acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][m >> 2], fb[i & 1][m & 3], acc[m >> 2][m & 3], 0, 0, 0);
+                if (i + 1 < 4 * TPS && m < 6) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  rd(i + 1, m, (i + 1) & 1);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+            }
+          } else
 #pragma unroll
           for (int k = 0; k < TPS; ++k) {
             const int tp = p.tap[TPS * g + k];
