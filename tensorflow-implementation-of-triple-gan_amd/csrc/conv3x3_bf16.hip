@@ -27,6 +27,7 @@
 // Numerics: every MFMA operand is rounded to bf16 (RNE) exactly as the generic tg_*_bf16 kernels do, products accumulate in fp32 —
 // the results differ from those kernels only by the order of the fp32 accumulation (channel chunks outermost here).
 #include <cstdlib>
+#include <type_traits>
 #include "tg_common.h"
 #include "tg_device.h"
 #include "tg_conv3x3_bf16.h"
@@ -64,7 +65,7 @@ __device__ unsigned long long tg_conv_stamps[8 * 64];
 #endif
 
 #ifndef TG_C3_PIPE
-#define TG_C3_PIPE 1                           // bf16 consumers: fragment reads software-pipelined behind the MFMAs (0 = the compiler's order; A/B builds)
+#define TG_C3_PIPE 1                           // consumers: fragment reads software-pipelined behind the MFMAs — 1: bf16 operands only (shipped), 2: fp32 too (measured 1.5 - 2 % SLOWER: profiles/r04_c3pipe_ab.txt), 0: the compiler's order
 #endif
 #ifndef TG_ABL
 #define TG_ABL 0                               // timing ablations of conv3x3_pipe_kernel (tools only, results then wrong): 1 no stores, 8 half the halo loads, 16 half the filter loads, 32 no MFMAs
@@ -421,12 +422,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
           const bool last_g = g == NG - 1;
           const bool more = !(last_g && last_c) || has_next;
           const unsigned char* B = Bs + bbuf * B_BYTES;
-          if constexpr (BF16 && TG_C3_PIPE) {
-            // A bf16 MFMA holds the pipe for 32 cycles and a wave issues in order: six fragment reads in front of every eight MFMAs left the
-            // pipe idle ~80 cycles per sub-step (stamps: 4 055 cycles per step outside the barriers against 3 072 of MFMAs).  Here the twelve
-            // (tap, k-slice) sub-steps of a step are one software pipeline over two fragment register sets: the six reads of sub-step
-            // i + 1 are issued one each behind the first six MFMAs of sub-step i (in the order their MFMAs need them), so only the first
-            // reads of a step — behind its barrier — are waited for.
+          if constexpr (TG_C3_PIPE == 2 || (TG_C3_PIPE == 1 && BF16)) {
+            // A wave issues in order: six fragment reads in front of the MFMAs of a (tap, k-slice) sub-step left the pipe idle for an LDS
+            // latency, ~90 cycles per sub-step (stamps, conv1_2: fp32 26 084 cycles per step against 24 576 of MFMAs, bf16 4 829 against
+            // 3 072 with 774 at the barriers).  Here the twelve sub-steps of a step are one software pipeline over two fragment register
+            // sets: the six reads of sub-step i + 1 are issued one each behind the first six MFMAs of sub-step i (in the order their
+            // MFMAs need them), so only the first reads of a step — behind its barrier — are waited for.  bf16: +1 ... 5 % (the launch is paced
+            // by its loaders); fp32 (TG_C3_PIPE=2): 1.5 - 2 % slower than the compiler's order, not shipped.
+            using frag_t = typename std::conditional<BF16, bf16x8, f32x4>::type;
+            constexpr int NM = BF16 ? 8 : 32;                     // MFMAs per sub-step: 2 x 4 tiles (x 4 k-pairs of the fp32 fragment)
             int a_row[TPS][2], a_swz[TPS][2];
 #pragma unroll
             for (int k = 0; k < TPS; ++k) {
@@ -439,14 +443,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
                 a_swz[k][mi] = (hp >> 1) & 7;
               }
             }
-            bf16x8 fa[2][2], fb[2][4];
+            frag_t fa[2][2], fb[2][4];
             auto rd = [&](int i, int j, int set) {                // read j of sub-step i: a0, b0, b1, b2, b3, a1
               const int k = i >> 2, s = i & 3;
               if (j == 0 || j == 5) {
                 const int mi = j == 0 ? 0 : 1;
-                fa[set][mi] = *reinterpret_cast<const bf16x8*>(As + a_row[k][mi] + (((2 * s + half) ^ a_swz[k][mi]) << 4));
+                fa[set][mi] = *reinterpret_cast<const frag_t*>(As + a_row[k][mi] + (((2 * s + half) ^ a_swz[k][mi]) << 4));
               } else {
-                fb[set][j - 1] = *reinterpret_cast<const bf16x8*>(B + k * B_TAP + b_off[j - 1] + (((2 * s + half) ^ b_swz) << 4));
+                fb[set][j - 1] = *reinterpret_cast<const frag_t*>(B + k * B_TAP + b_off[j - 1] + (((2 * s + half) ^ b_swz) << 4));
               }
             };
 #pragma unroll
@@ -454,11 +458,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pipe_kernel(ConvParams p) {
 #pragma unroll
             for (int i = 0; i < 4 * TPS; ++i) {
 #pragma unroll
-              for (int m = 0; m < 8; ++m) {
-                acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][m >> 2], fb[i & 1][m & 3], acc[m >> 2][m & 3], 0, 0, 0);
-                if (i + 1 < 4 * TPS && m < 6) {
+              for (int q = 0; q < NM; ++q) {
+                const int mi = (q >> 2) & 1, ni = q & 3;
+                if constexpr (BF16) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][mi], fb[i & 1][ni], acc[mi][ni], 0, 0, 0);   // D[pixel][channel]: lane = channel
+                else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i & 1][mi][q >> 3], fb[i & 1][ni][q >> 3], acc[mi][ni], 0, 0, 0);
+                if (i + 1 < 4 * TPS && q < 6) {
                   __builtin_amdgcn_sched_barrier(0);
-                  rd(i + 1, m, (i + 1) & 1);
+                  rd(i + 1, q, (i + 1) & 1);
                   __builtin_amdgcn_sched_barrier(0);
                 }
               }
