@@ -16,6 +16,7 @@ _NARROW = _os.environ.get('TG_NARROW_DECONV', '1') != '0'     # A/B switch of cs
 _ACTSUM = _os.environ.get('TG_ACTSUM', '1') != '0'      # A/B switch of the input-gradient + activation-derivative + column-sum fusion
 _MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_igemm_actsum_f32', 'tg_igemm_bnstat_f32', 'tg_igemm_bnbwdstat_f32', 'tg_wgrad_f32',
              'tg_igemm_labels_f32')
+_WIDE_SIDE = _os.environ.get('TG_WIDE_SIDE', '1') != '0'         # A/B switch: the many-split filter gradients of small filters (and their reduction) on the second stream
 _POOL_FUSE = _os.environ.get('TG_POOL_FUSE', '1') != '0'         # A/B switch: mean-only-BN apply + max-pool 2x2 + dropout in one launch (tg_mobn_apply_pool_f32)
 _CONCAT_FUSE = _os.environ.get('TG_CONCAT_FUSE', '1') != '0'     # A/B switch: conv -> cond_concat pairs written by the convolution's own epilogue (tg_igemm_labels_*)
 
@@ -109,6 +110,16 @@ def filter_grad(desc, in_act_t, dout_t, t, c_dim, n_dim, dst, wn=None, defer=Tru
     if deferred and (small or cx.wgrad_side_all) and not wide:
         with cx.wgrad_on_side():                                 # beside the input-gradient chain (Context.wgrad_on_side; joined in flush_tails)
             _call('tg_wgrad_f32', desc, _p(in_act_t), _p(dout_t), _p(slab), ns, cx.stream)
+    elif deferred and small and wide and _WIDE_SIDE:
+        # many splits of a small filter (the discriminator's first layers, the classifier's first): the launch AND its own reduction go to
+        # the second stream, so the input-gradient chain does not wait for them (round 4: they were 0.18 ms of the D-update's launch stream)
+        with cx.wgrad_on_side():
+            _call('tg_wgrad_f32', desc, _p(in_act_t), _p(dout_t), _p(slab), ns, cx.stream)
+            _call('tg_slab_reduce_f32', _p(slab), ns, t, desc.ld_in, desc.c_out, c_dim, n_dim, _p(dst), cx.stream)
+            if wn is not None:
+                coef = cx.scratch('coef', 2 * n_dim)
+                _call('tg_wn_bwd_f32', _p(dst), _p(wn[0]), _p(wn[1]), t * c_dim, n_dim, _p(wn[2]), _p(wn[3]), _p(coef), cx.stream)
+        return
     else:
         _call('tg_wgrad_f32', desc, _p(in_act_t), _p(dout_t), _p(slab), ns, cx.stream)
     if deferred and not wide:
