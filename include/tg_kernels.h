@@ -177,9 +177,9 @@ int tg_igemm_colsum_bf16(const tg_igemm_desc* d, const float* in, const float* w
 int tg_wgrad_bf16(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream);
 
 /* Backward pass of a 5x5 / stride-2 / 'same' transposed convolution with c_out <= 4 output channels (the generator's image layer,
- * Model/Good_GAN_cifar10.py:55-57, Model/modle_base.py:246-259) on the vector ALUs — the MFMA tiles pad 3 channels to 32 and do ten times
- * the layer's arithmetic.  dy: gradient at the layer's pre-activation output [n, 2h, 2w, ld_dy] (c_out channels used); x: the layer input
- * [n, h, w, ld_x] (ci_p = channel-padded width, a multiple of 32, <= 256; 16 | w, 4 | h).
+ * Model/Good_GAN_cifar10.py:55-57, Model/modle_base.py:246-259) as K-PACKED fp32 MFMA products (contraction index = the (tap, channel)
+ * pair: 75 for three channels) — the generic tiles pad 3 channels to 32 and do ten times the layer's arithmetic.  dy: gradient at the layer's pre-activation output [n, 2h, 2w, ld_dy] (c_out channels used); x: the layer input
+ * [n, h, w, ld_x] (ci_p = channel-padded width, a multiple of 32, <= 256; 16 | w, w <= 32, 4 | h).
  *   dgrad: dx[n,i,j,ci] = sum_{ky,kx,co} dy[n, 2i+ky-1, 2j+kx-1, co] * W[ky,kx,co,ci], W = the [5,5,Cout,Cin] variable itself, times
  *          scale_a[co] when not NULL (weight norm: tg_wn_scale_tab_f32); all ci_p channels of dx are written (zeros beyond c_in).
  *   wgrad: dw[25][c_out][c_in] = sum_{n,i,j} dy[n, 2i+ky-1, 2j+kx-1, co] * x[n,i,j,ci] — the layout of the [5,5,Cout,Cin] variable;

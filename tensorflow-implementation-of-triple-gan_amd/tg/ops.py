@@ -355,7 +355,7 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
         if wn is not None:
             scale_a = cx.scratch('wnsa', c_out)
             _call('tg_wn_scale_tab_f32', _p(kernel), _p(wn[0]), 25, c_out, c_in, _p(scale_a), cx.stream)
-        # the 3-channel image layer's backward runs on the vector ALUs straight from the [5,5,Cout,Cin] variable (csrc/narrow.hip): no transposed copy
+        # the 3-channel image layer's backward runs as K-packed products straight from the [5,5,Cout,Cin] variable (csrc/narrow.hip): no transposed copy
         narrow = _NARROW and x.ld == ci_p and bool(lib.call('tg_deconv5x5s2_narrow_supported', x.n, x.h, x.w, c_out, ci_p))
         w_tr = cx.scratch('wtr', 25 * ci_p * co_p) if (needs_x and not narrow) else None
         if merged:
@@ -399,7 +399,7 @@ def deconv2d(x, kernel, bias, c_out, act=None, kernel_grad=None, bias_grad=None,
                   ACT[act], 0.2, cx.stream)
             if needs_w and bias_grad is not None:
                 colstats(0, dpre, co_p, None, 0, y.rows, c_out, [y.rows], s1=bias_grad)
-        # the 3-channel image layer: both gradients on the vector ALUs (csrc/narrow.hip) — the MFMA tiles would pad 3 channels to 32
+        # the 3-channel image layer: both gradients as K-packed products (csrc/narrow.hip) — the generic tiles would pad 3 channels to 32
         if needs_w:
             dw = kernel_grad if wn is None else cx.scratch('dw', 25 * c_out * c_in)
             if narrow:

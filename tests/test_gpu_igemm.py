@@ -367,9 +367,9 @@ def test_cut_tiles_with_column_sums_and_activation_gradient(prec, n, hw, ci, co,
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(5, 16, 16, 138, 3), (2, 32, 32, 74, 3), (3, 4, 16, 40, 1), (2, 8, 16, 120, 4)])
-def test_narrow_transposed_conv_backward_on_the_vector_alus(n, h, w, cin, cout):
+def test_narrow_transposed_conv_backward_k_packed(n, h, w, cin, cout):
     """csrc/narrow.hip: input and filter gradient of a 5x5 / stride-2 transposed conv with <= 4 output channels (the generator's image
-    layer) against the oracle — exact fp32 FMAs, so the fp32 bound of the MFMA kernels applies."""
+    layer) against the oracle — K-packed fp32 MFMA products (exact fp32 products), so the fp32 bound of the MFMA kernels applies."""
     lib, geom = _tg()
     rng = np.random.default_rng(11)
     ci_p, co_p = geom.pad32(cin), geom.pad32(cout)
