@@ -196,12 +196,22 @@ def test_error_rate_ensemble_against_the_cpu_reference_runs(fixture):
         h_settle = settling_step(steps, list(he), level)
         assert abs(h_settle - np.mean(c_settle)) <= settle_tol, (r['name'], 'settling iteration', h_settle, sorted(c_settle), settle_tol, table)
         # the losses stay on the controls' scale (GAN losses fluctuate: bound = the controls' spread around float64 over the neighbouring
-        # 25 iterations, per loss)
+        # 25 iterations, per loss).  A GAN loss also SPIKES for an iteration or two and recovers — the float32 controls do (fixture 'ref':
+        # D loss 1.88 against a running level of 1.05) — and the twelve sampled iterations of a run can land on one: one sampled point per
+        # run may exceed the bound, none by more than three times, and the largest loss of the whole run stays within 1.5x of the controls'.
         losses = r['losses']
+        assert np.isfinite(losses).all(), r['name']
+        over = []
         for k in range(24, len(losses), 25):
             lo, hi = max(0, k - 25), min(len(losses), k + 25)
             allowed = 2.0 * dev[lo:hi].max(axis=0) + ref[lo:hi].std(axis=0) + 0.05
-            assert np.all(np.abs(losses[k] - ref[k]) <= allowed), (r['name'], k + 1, losses[k], ref[k], allowed)
+            d_k = np.abs(losses[k] - ref[k])
+            assert np.all(d_k <= 3.0 * allowed), (r['name'], k + 1, losses[k], ref[k], allowed)
+            if not np.all(d_k <= allowed):
+                over.append((k + 1, losses[k].tolist(), ref[k].tolist(), allowed.tolist()))
+        assert len(over) <= 1, (r['name'], 'sampled losses beyond the controls\' spread', over)
+        c_max = np.max([np.abs(v['losses']).max(axis=0) for v in ctl.values()], axis=0)
+        assert np.all(np.abs(losses).max(axis=0) <= 1.5 * c_max + 0.05), (r['name'], np.abs(losses).max(axis=0), c_max)
     # 3. the acceptance number: ensemble mean against ensemble mean, and every member against the controls' mean
     for name, st in stats.items():
         assert abs(st['hip_mean'] - st['controls_mean']) <= st['bound_ensemble'], (name, 'ensemble', st)
