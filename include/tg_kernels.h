@@ -176,6 +176,23 @@ int tg_igemm_colsum_bf16(const tg_igemm_desc* d, const float* in, const float* w
                          double* colsum, int colsum_zeroed, void* scratch, int64_t scratch_bytes, void* stream);
 int tg_wgrad_bf16(const tg_igemm_desc* d, const float* in, const float* dout, float* slab, int n_split, void* stream);
 
+/* 3x3 / stride 1 / SAME convolution of FEW input channels (c_in <= 16; the discriminators' first layer: 3 image + 10 label channels -> 32,
+ * Model/Good_GAN_cifar10.py:63-66, Model/Good_GAN.py:129-132; tf.layers.conv2d, Model/modle_base.py:157-168) as K-PACKED fp32 MFMA products:
+ * the contraction index is the (tap, channel) pair, K = 9 c_in, instead of taps x 32 padded channels (csrc/packed_conv.hip).
+ * x: [n, h, w, ld_x] (c_in channels used); kernel: the [3,3,Cin,Cout] variable itself (no preparation launch); c_out = 32 or 64; 16 | w,
+ * w <= 32, 4 | h.
+ *   fwd:   y[n,i,j,co] = act(sum x[n,i+ky-1,j+kx-1,ci] W[ky,kx,ci,co] + bias[co]), act in {none, relu, leaky relu}; channels [c_out, ld_y) of
+ *          y are written too: labels[n][0 .. lab_n) (labels != NULL: the conv -> cond_concat pair in one launch, as tg_igemm_labels_*), zeros behind.
+ *   wgrad: dw[3,3,Cin,Cout] = sum_{n,i,j} x[n,i+ky-1,j+kx-1,ci] dy[n,i,j,co] — the variable's layout; dy: [n, h, w, ld_dy] (4 | ld_dy);
+ *          workspace: tg_conv3x3_packed_wgrad_workspace_bytes bytes of caller-owned scratch (per-block partial sums, reduced in a fixed order).
+ * tg_conv3x3_packed_supported: 1 when the shape is served (else use tg_igemm_* / tg_wgrad_*). */
+int tg_conv3x3_packed_supported(int n, int h, int w, int c_in, int c_out);
+int64_t tg_conv3x3_packed_wgrad_workspace_bytes(int n, int h, int w, int c_in, int c_out);
+int tg_conv3x3_packed_fwd_f32(const float* x, int ld_x, int c_in, const float* kernel, const float* bias, int act, float alpha, const float* labels,
+                              int lab_n, float* y, int ld_y, int n, int h, int w, int c_out, void* stream);
+int tg_conv3x3_packed_wgrad_f32(const float* x, int ld_x, int c_in, const float* dy, int ld_dy, int n, int h, int w, int c_out, float* workspace,
+                                float* dw, void* stream);
+
 /* Backward pass of a 5x5 / stride-2 / 'same' transposed convolution with c_out <= 4 output channels (the generator's image layer,
  * Model/Good_GAN_cifar10.py:55-57, Model/modle_base.py:246-259) as K-PACKED fp32 MFMA products (contraction index = the (tap, channel)
  * pair: 75 for three channels) — the generic tiles pad 3 channels to 32 and do ten times the layer's arithmetic.  dy: gradient at the layer's pre-activation output [n, 2h, 2w, ld_dy] (c_out channels used); x: the layer input

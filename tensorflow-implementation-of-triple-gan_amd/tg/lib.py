@@ -58,9 +58,10 @@ _SCALARS = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint32_
 _RET = {"int": C.c_int, "int64_t": C.c_int64, "const char*": C.c_char_p}
 _NOCHECK = {"tg_version", "tg_last_error_string", "tg_device_count", "tg_prof_num_classes", "tg_prof_class_name",
             "tg_colstats_workspace_floats", "tg_igemm_colsum_supported", "tg_conv3x3_policy", "tg_conv3x3_launches",
-            "tg_deconv5x5s2_narrow_supported"}
+            "tg_deconv5x5s2_narrow_supported", "tg_conv3x3_packed_supported"}
 _NEGATIVE_IS_ERROR = {"tg_wgrad_splits", "tg_wgrad_splits_bf16", "tg_wgrad_workspace_bytes", "tg_filter_workspace_bytes",
-                      "tg_igemm_workspace_bytes", "tg_deconv5x5s2_narrow_wgrad_workspace_bytes"}     # return a count / size, < 0 on error
+                      "tg_igemm_workspace_bytes", "tg_deconv5x5s2_narrow_wgrad_workspace_bytes",
+                      "tg_conv3x3_packed_wgrad_workspace_bytes"}     # return a count / size, < 0 on error
 HOST_INT_ARRAYS = {"seg_rows", "tapmap"}          # pointer arguments that are HOST arrays
 
 

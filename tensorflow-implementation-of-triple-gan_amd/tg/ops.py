@@ -16,6 +16,7 @@ _NARROW = _os.environ.get('TG_NARROW_DECONV', '1') != '0'     # A/B switch of cs
 _ACTSUM = _os.environ.get('TG_ACTSUM', '1') != '0'      # A/B switch of the input-gradient + activation-derivative + column-sum fusion
 _MFMA_F32 = ('tg_igemm_f32', 'tg_igemm_multi_f32', 'tg_igemm_colsum_f32', 'tg_igemm_actsum_f32', 'tg_igemm_bnstat_f32', 'tg_igemm_bnbwdstat_f32', 'tg_wgrad_f32',
              'tg_igemm_labels_f32')
+_PACKED = _os.environ.get('TG_PACKED_CONV', '1') != '0'       # A/B switch of csrc/packed_conv.hip (3x3 convolutions of <= 16 input channels: the discriminators' first layer)
 _WIDE_SIDE = _os.environ.get('TG_WIDE_SIDE', '1') != '0'         # A/B switch: the many-split filter gradients of small filters (and their reduction) on the second stream
 _POOL_FUSE = _os.environ.get('TG_POOL_FUSE', '1') != '0'         # A/B switch: mean-only-BN apply + max-pool 2x2 + dropout in one launch (tg_mobn_apply_pool_f32)
 _CONCAT_FUSE = _os.environ.get('TG_CONCAT_FUSE', '1') != '0'     # A/B switch: conv -> cond_concat pairs written by the convolution's own epilogue (tg_igemm_labels_*)
@@ -204,6 +205,9 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
     pooled = None
     seg_rows = _segs(y, segments)
     fused = (mobn is not None and train and c_out == co_p and c_out <= 512 and stride == 1 and geom.colsum_supported(d, seg_rows))
+    packed = (_PACKED and cx.mfma_dtype != 'bf16' and k == 3 and stride == 1 and padding == 'SAME' and wn is None and mobn is None and not bn_stats
+              and n_store_ld is None and c_out == co_p and act in (None, 'relu', 'lrelu') and c_in <= 16
+              and bool(_call('tg_conv3x3_packed_supported', x.n, x.h, x.w, c_in, c_out)))
     if fused:
         # convolution + per-(application, channel) sums in one launch, then one fused apply pass (mean, +b, activation, pop_mean)
         b, b_grad, pop = mobn
@@ -221,6 +225,12 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
         bsum, zd = cx.zscratch('bn64', 32 * len(seg_rows) * c_out)     # the batch norm's buffer: 8 replicas x nseg x 2 x c doubles
         _call('tg_igemm_bnstat_f32', d, x.ptr, _p(w_oti), _p(bias), y.ptr, seg_array(seg_rows), len(seg_rows), _p(bsum), zd, cx.stream)
         y.bn_sums = (bsum, tuple(seg_rows))
+    elif packed:
+        # K-packed products straight from the [3,3,Cin,Cout] variable (csrc/packed_conv.hip); with concat the label channels ride along
+        _call('tg_conv3x3_packed_fwd_f32', x.ptr, x.ld, c_in, _p(kernel), _p(bias), ACT[act], alpha, _p(concat[0]) if fuse_cat else None,
+              concat[1] if fuse_cat else 0, y.ptr, ld_out, x.n, x.h, x.w, c_out, cx.stream)
+        if fuse_cat:
+            y.labels = (concat[0].data_ptr(), concat[1])
     elif fuse_cat:
         _call('tg_igemm_labels_f32', d, x.ptr, _p(w_oti), _p(bias), _p(concat[0]), concat[1], y.ptr, cx.stream)
         y.labels = (concat[0].data_ptr(), concat[1])
@@ -284,7 +294,11 @@ def conv2d(x, kernel, bias, c_out, k, stride, padding, act=None, alpha=0.2, wn=N
                   ACT[act], alpha, cx.stream)
             if needs_w and bias_grad is not None:
                 colstats(0, dpre, co_p, None, 0, y.rows, c_out, [y.rows], s1=bias_grad)
-        if needs_w:
+        if needs_w and packed:
+            pws = cx.scratch('pkws', _call('tg_conv3x3_packed_wgrad_workspace_bytes', x.n, x.h, x.w, c_in, c_out) // 4)
+            with cx.wgrad_on_side():                      # beside the input-gradient chain; joined in flush_tails
+                _call('tg_conv3x3_packed_wgrad_f32', x.ptr, x.ld, c_in, _p(dpre), co_p, x.n, x.h, x.w, c_out, _p(pws), _p(kernel_grad), cx.stream)
+        elif needs_w:
             dw_desc = geom.conv_wgrad(x.n, x.h, x.w, ci_p, co_p, k, stride, padding)
             if wn is None:
                 filter_grad(dw_desc, x.t, dpre, t, c_in, c_out, kernel_grad)

@@ -432,3 +432,48 @@ def test_conv_writes_the_cond_concat_behind_it(n, h, cin, cout, s, prec):
     bad = geom.conv_fwd(n, h, h, ci_p, co_p, 3, s, 'SAME', ld_out=co_p, n_store=cout, act='lrelu')
     with pytest.raises(lib.TgError, match='igemm_labels'):
         lib.call_igemm("tg_igemm_labels_" + prec, bad, lib.ptr(xd), lib.ptr(wd), lib.ptr(bd), lib.ptr(ld_), 10, lib.ptr(yd), lib.cur_stream())
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,nlab", [(5, 32, 32, 13, 32, 10), (3, 16, 16, 3, 64, 0), (2, 8, 32, 16, 32, 10), (2, 12, 16, 7, 32, 4)])
+def test_few_channel_3x3_conv_k_packed(n, h, w, cin, cout, nlab):
+    """csrc/packed_conv.hip: forward (+ bias, leaky relu, the cond-concat's label channels and the channel padding behind them) and filter
+    gradient of a 3x3 / stride-1 / SAME convolution with <= 16 input channels (the discriminators' first layer, 13 -> 32) as K-packed fp32
+    MFMA products straight from / into the [3,3,Cin,Cout] variable, against the oracle — exact fp32 products: the fp32 bound of the MFMA
+    kernels, and the negative control (bf16-rounded operands) misses it."""
+    lib, geom = _tg()
+    rng = np.random.default_rng(41)
+    assert lib.call('tg_conv3x3_packed_supported', n, h, w, cin, cout) == 1
+    assert lib.call('tg_conv3x3_packed_supported', n, h, w, 17, cout) == 0 and lib.call('tg_conv3x3_packed_supported', n, h, w, cin, 128) == 0
+    assert lib.call('tg_conv3x3_packed_supported', n, h, 24, cin, cout) == 0
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    lab = rng.random((n, max(nlab, 1))).astype(np.float32)
+    dy = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+    ci_p, ld = geom.pad32(cin), geom.pad32(cout + nlab)
+    st = lib.cur_stream()
+    xd, wd, bd, labd = dev(padc(x, ci_p)), dev(wt), dev(bias), dev(lab)
+    other = lambda a: T.bf16_round(a)
+    for act, fn in (('lrelu', T.lrelu), (None, lambda v: v)):
+        y_ref = fn(T.conv2d(f8(x), f8(wt), (1, 1), 'SAME') + f8(bias))
+        y_abs = T.conv2d(np.abs(f8(x)), np.abs(f8(wt)), (1, 1), 'SAME') + np.abs(f8(bias))
+        yd = torch.full((n, h, w, ld), 7.0, device='cuda')
+        lib.call('tg_conv3x3_packed_fwd_f32', lib.ptr(xd), ci_p, cin, lib.ptr(wd), lib.ptr(bd), lib.ACT[act], 0.2, lib.ptr(labd) if nlab else None, nlab,
+                 lib.ptr(yd), ld, n, h, w, cout, st)
+        y = yd.cpu().numpy()
+        close(y[..., :cout], y_ref, y_abs)
+        assert rejected(y[..., :cout], fn(T.conv2d(f8(other(x)), f8(other(wt)), (1, 1), 'SAME') + f8(bias)), y_abs)
+        if nlab:
+            np.testing.assert_array_equal(y[..., cout:cout + nlab], np.broadcast_to(lab[:, None, None, :], (n, h, w, nlab)))      # the labels, bit for bit
+        assert (y[..., cout + nlab:] == 0).all()
+    # filter gradient straight into the [3,3,Cin,Cout] variable's layout
+    need = lib.call('tg_conv3x3_packed_wgrad_workspace_bytes', n, h, w, cin, cout)
+    ws = torch.empty(need // 4, device='cuda')
+    dwd = torch.full((3, 3, cin, cout), 7.0, device='cuda')
+    dyd = dev(padc(dy, geom.pad32(cout)))
+    lib.call('tg_conv3x3_packed_wgrad_f32', lib.ptr(xd), ci_p, cin, lib.ptr(dyd), geom.pad32(cout), n, h, w, cout, lib.ptr(ws), lib.ptr(dwd), st)
+    dw_abs = T.conv2d_bwd_filter(np.abs(f8(x)), np.abs(f8(dy)), wt.shape, (1, 1), 'SAME')
+    close(dwd.cpu().numpy(), T.conv2d_bwd_filter(f8(x), f8(dy), wt.shape, (1, 1), 'SAME'), dw_abs)
+    assert rejected(dwd.cpu().numpy(), T.conv2d_bwd_filter(f8(other(x)), f8(other(dy)), wt.shape, (1, 1), 'SAME'), dw_abs)
+    with pytest.raises(lib.TgError, match='conv3x3_packed_fwd'):
+        lib.call('tg_conv3x3_packed_fwd_f32', lib.ptr(xd), ci_p, cin, lib.ptr(wd), lib.ptr(bd), lib.ACT['lrelu'], 0.2, lib.ptr(labd), 40, lib.ptr(yd), ld, n, h, w, cout, st)
