@@ -447,11 +447,22 @@ class Train(Train_base):
         in between.  Only reached when tg.dist.graphs_allowed(): the exchange backends used with graphs (rccl-direct, gloo) have no
         thread that touches HIP events behind the trainer's back, so a capture cannot be disturbed (tg/dist.py docstring)."""
         import ctypes as C
+        import gc
         cx = self.cx
         cx.prep_cache = {}
         cx.plan_tag = key
         for st in cx.stores.values():
             st.frozen = True                     # the graphs hold these buffers' addresses: ParamStore.extend must not re-allocate them
+        # No garbage collection inside a capture window.  A collector pass can free a PINNED host tensor of an earlier owner (an input
+        # pipeline's staging slots): torch's caching host allocator then records an event on every stream the tensor was copied on — torch
+        # hands out streams from a pool of 32, so in a long-lived process that can be THIS trainer's capturing stream — and its next query of
+        # that captured event fails with "operation not permitted when stream is capturing", which invalidates the capture (every later
+        # launch: "operation failed due to a previous error during capture").  Seen once in a full test session (round 4); mechanism
+        # reproduced in tools/micro/capture_pinned_free.py.
+        gc_was = gc.isenabled()
+        if not os.environ.get('TG_DEBUG_CAPTURE_GC'):      # (test hook: leave the collector running, to show what the guard is for)
+            gc.collect()
+            gc.disable()
         try:
             for i, (fn, _grads, _wait) in enumerate(segs):
                 if graphs[i] is not None:
@@ -469,6 +480,8 @@ class Train(Train_base):
                 graphs[i] = h
         finally:
             cx.prep_cache = None
+            if gc_was:
+                gc.enable()
 
     def losses(self):
         """(d_loss, g_loss, c_loss) of the last iteration — a device->host sync; call sparingly."""

@@ -188,3 +188,30 @@ def test_launch_plan_api_on_two_streams_and_its_error_report():
         bad.replay()
     torch.cuda.synchronize()
     assert float(a[:16].max()) == 1.0                    # the operation in front of the failing one was issued
+
+
+def test_capture_survives_the_garbage_of_earlier_owners():
+    """Train._capture keeps Python's garbage collector out of the capture window: a collector pass can free pinned host tensors of earlier
+    owners, torch's host allocator then records and queries an event on the streams they were copied on — if that is the capturing stream
+    (torch's stream pool wraps around after 32) the capture is invalidated (tools/micro/capture_pinned_free.py shows the mechanism).  Here
+    cyclic garbage holding streams, events, device and pinned tensors waits for collection and the collector is set to run every few
+    allocations while an iteration is captured."""
+    import gc
+    import torch
+    l_ref, p_ref, _ = run(True, steps=3)
+    for _ in range(16):
+        s, e = torch.cuda.Stream(), torch.cuda.Event()
+        e.record(s)
+        cyc = [s, e, torch.empty(1024, device='cuda'), torch.empty(1 << 16).pin_memory()]
+        cyc.append(cyc)
+    del s, e, cyc
+    old = gc.get_threshold()
+    gc.set_threshold(5, 1, 1)
+    try:
+        l_g, p_g, g_g = run(True, steps=3)
+    finally:
+        gc.set_threshold(*old)
+    assert all(h is not None for h in g_g['full'])
+    assert l_g == l_ref
+    for net in p_ref:
+        np.testing.assert_array_equal(p_ref[net], p_g[net])
