@@ -147,6 +147,25 @@ __global__ void __launch_bounds__(256) slab_reduce_multi(WnJobs js) {
   const tg_wn_job& J = js.j[blockIdx.y];
   const int64_t total = (int64_t)J.t * J.c_in * J.c_out;
   const int64_t sstride = (int64_t)J.t * J.c_pad * J.n_pad;
+  if ((J.c_out & 3) == 0 && (J.n_pad & 3) == 0 && ((reinterpret_cast<uintptr_t>(J.slab) | reinterpret_cast<uintptr_t>(J.dw)) & 15) == 0) {
+    // four consecutive columns per thread: 16-byte loads (a quarter of the requests for the same bytes: the classifier's slabs are 190 MB
+    // per step); every output is still the sum of its n_split partials in slab order — bit-identical to the scalar form below
+    const int64_t total4 = total >> 2;
+    const int q = J.c_out >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+      const int n4 = (int)(i % q);
+      const int64_t tc = i / q;
+      const int c = (int)(tc % J.c_in), t = (int)(tc / J.c_in);
+      const float* p = J.slab + ((int64_t)t * J.c_pad + c) * J.n_pad + 4 * n4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = 0; s < J.n_split; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(p + s * sstride);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4*>(J.dw + 4 * i) = acc;
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(i % J.c_out);
     const int64_t tc = i / J.c_out;
