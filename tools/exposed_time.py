@@ -6,7 +6,7 @@ the kernel that has been running longest at that instant — and (c) nothing run
 """
 import collections, csv, glob, os, re, sys
 
-MFMA = ('conv3x3_pipe_kernel', 'igemm_f32_kernel', 'wgrad3x3_kernel', 'wgrad_f32_kernel')
+MFMA = ('conv3x3_pipe_kernel', 'igemm_f32_kernel', 'wgrad3x3_kernel', 'wgrad_f32_kernel', 'packed_fwd', 'packed_wgrad<', 'narrow_dgrad', 'narrow_wgrad<')
 MARK = os.environ.get('TG_TRACE_MARK', 'narrow_dgrad')    # a kernel launched PER times per iteration (default: generator image layer, G-update)
 PER = int(os.environ.get('TG_TRACE_MARK_PER', '1'))
 
