@@ -45,20 +45,43 @@ __global__ void __launch_bounds__(256) narrow_dgrad(const float* __restrict__ dy
   const int i0 = ty * DROWS, j0 = tx * 16;
   const int tid = threadIdx.x, lane = tid & 31, pg = tid >> 5;
   const int nq = ci_p / 32;
-  for (int tc = pg; tc < KP; tc += 8) {              // half-wave = one filter row: coalesced 128-byte reads
-    const float sc = (scale_a && tc < K) ? scale_a[tc % CO] : 1.f;
+  // (staging loads go out in groups — two filter rows x nq units, eight patch elements — before anything is stored: one load per loop trip made
+  // the prologue a chain of memory latencies)
+  for (int tc0 = pg; tc0 < KP; tc0 += 16) {          // half-wave = one filter row: coalesced 128-byte reads
+    float v[2][MAXQ];
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q)
-      if (q < nq) {
+    for (int u = 0; u < 2; ++u) {
+      const int tc = tc0 + 8 * u;
+      const float sc = (scale_a && tc < K) ? scale_a[tc % CO] : 1.f;
+#pragma unroll
+      for (int q = 0; q < MAXQ; ++q) {
         const int ci = lane + 32 * q;
-        Wl[tc * ci_p + ci] = (tc < K && ci < c_in) ? kernel[(int64_t)tc * c_in + ci] * sc : 0.f;
+        v[u][q] = (q < nq && tc < K && ci < c_in) ? kernel[(int64_t)tc * c_in + ci] * sc : 0.f;
       }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int tc = tc0 + 8 * u;
+#pragma unroll
+      for (int q = 0; q < MAXQ; ++q)
+        if (q < nq && tc < KP) Wl[tc * ci_p + lane + 32 * q] = v[u][q];
+    }
   }
   const int H2 = 2 * h, W2 = 2 * w;
-  for (int e = tid; e < PR * PC * CO; e += 256) {
-    const int co = e % CO, c = (e / CO) % PC, r = e / (CO * PC);
-    const int oy = 2 * i0 - 1 + r, ox = 2 * j0 - 1 + c;
-    Pl[e] = ((unsigned)oy < (unsigned)H2 && (unsigned)ox < (unsigned)W2) ? dy[(((int64_t)n * H2 + oy) * W2 + ox) * ld_dy + co] : 0.f;
+  for (int e0 = tid; e0 < PR * PC * CO; e0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u;
+      const int co = e % CO, c = (e / CO) % PC, r = e / (CO * PC);
+      const int oy = 2 * i0 - 1 + r, ox = 2 * j0 - 1 + c;
+      v[u] = (e < PR * PC * CO && (unsigned)oy < (unsigned)H2 && (unsigned)ox < (unsigned)W2) ? dy[(((int64_t)n * H2 + oy) * W2 + ox) * ld_dy + co] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u;
+      if (e < PR * PC * CO) Pl[e] = v[u];
+    }
   }
   if (tid < KP) {
     const int tap = tid / CO, co = tid - tap * CO, ky = tap / 5, kx = tap - ky * 5;

@@ -38,14 +38,36 @@ __global__ void __launch_bounds__(256) packed_fwd(const float* __restrict__ x, i
   const int n = b / tiles_y;
   const int i0 = ty * FROWS, j0 = tx * 16;
   const int tid = threadIdx.x;
-  for (int e = tid; e < KP * CO; e += 256) Wl[e] = e < K * CO ? wk[e] : 0.f;
+  // staging in groups of eight loads per thread: issued together, stored together (one load per loop trip made a workgroup's prologue a chain
+  // of ~25 memory latencies: 48 us per 250-image launch, most of it here)
+  for (int e0 = tid; e0 < KP * CO; e0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u;
+      v[u] = e < K * CO ? wk[e] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u;
+      if (e < KP * CO) Wl[e] = v[u];
+    }
+  }
   {
     const int ci = tid & 15;
-    for (int p = tid >> 4; p < PR * PCOLS; p += 16) {
+    constexpr int NP = (PR * PCOLS + 15) / 16;       // 12 passes of 16 patch pixels
+    float v[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int p = (tid >> 4) + 16 * u;
       const int r = p / PCOLS, c = p - r * PCOLS;
       const int iy = i0 - 1 + r, ix = j0 - 1 + c;
-      if (ci < c_in)
-        Pl[p * c_in + ci] = ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? x[(((int64_t)n * h + iy) * w + ix) * ld_x + ci] : 0.f;
+      v[u] = (p < PR * PCOLS && ci < c_in && (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? x[(((int64_t)n * h + iy) * w + ix) * ld_x + ci] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int p = (tid >> 4) + 16 * u;
+      if (p < PR * PCOLS && ci < c_in) Pl[p * c_in + ci] = v[u];
     }
   }
   if (tid < KP) {
